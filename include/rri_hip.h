@@ -1,0 +1,173 @@
+/*
+ * rri_hip.h -- C ABI of librri_hip.so: the MI355X (gfx950) implementation of the
+ * rank-one residue iteration (RRI) inner loop of maksimt/rri_nmf.
+ *
+ * The reference has no FFI: its seams are the Python callable
+ *     nmf(X, k, ...) -> dict                       src/rri_nmf/nmf.py:98-108, :551-560
+ * and the per-topic helpers it calls through **locals():
+ *     _compute_update_T                            nmf.py:633-715
+ *     _compute_update_W                            nmf.py:718-747
+ *     qf_min                                       optimization.py:12-88
+ *     euclidean_proj_simplex / proj_mat_to_simplex matrixops.py:5-100
+ *     _project_and_check_reset_t / _check_reset_W  nmf.py:751-816
+ *     TrueObjComputer.true_objective               nmf.py:71-94
+ * A maintainer of the reference would bind exactly the entry points below with
+ * ctypes (INTEGRATION.md shows the stub) and call them from nmf()'s sweep loop.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; every function returns an rri_status (0 = ok),
+ *     never throws; rri_last_error() gives the text of the last failure on a handle.
+ *   - host matrices are row-major, caller-owned and never written unless the
+ *     argument is an explicit output; `ld` arguments are row strides in ELEMENTS.
+ *   - one opaque handle per nmf() call; calls on one handle are serialised by the
+ *     caller; all device work of a handle runs on ONE HIP stream (its own, or the
+ *     caller's when `stream` is non-NULL, e.g. torch's current stream).
+ *   - notation follows the reference: X n*d, W n*k ("documents x topics"),
+ *     T k*d ("topics x features"; north_star's H).  W[:,t] is Ho's u_t, T[t,:] is v_t^T.
+ */
+#ifndef RRI_HIP_H
+#define RRI_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRI_ABI_VERSION 1
+
+typedef struct rri_ctx rri_ctx; /* opaque */
+
+typedef int32_t rri_status;
+enum {
+    RRI_OK = 0,
+    RRI_PAUSED = 1,             /* a sweep stopped at a rare branch; see rri_pending_event */
+    RRI_ERR_INVALID = -1,       /* bad argument / shape / state                              */
+    RRI_ERR_HIP = -2,           /* a HIP runtime call failed                                */
+    RRI_ERR_UNSUPPORTED = -3,   /* option not available on the device path                  */
+    RRI_ERR_UNBOUNDED = -4,     /* qf_min: minimum objective is unbounded (optimization.py:66-67,76-77) */
+    RRI_ERR_W_COL_ZERO = -5,    /* assert sum(W[:,t]) > 0 failed (nmf.py:476)               */
+    RRI_ERR_NOT_IMPLEMENTED = -6 /* qf_min: c<=0 with s not in {None,1.0} (optimization.py:72-73) */
+};
+
+enum { RRI_F32 = 0, RRI_F64 = 1 };                       /* arithmetic type of the path */
+enum { RRI_RESET_NONE = 0, RRI_RESET_MAX_RESID_DOCUMENT = 1, RRI_RESET_RANDOM = 2 };
+enum { RRI_EVENT_NONE = 0, RRI_EVENT_RESET_T = 1, RRI_EVENT_RESET_W = 2 };
+
+/* The options of nmf() that reach the inner loop (nmf.py:98-108).  "has_*" = the
+ * Python value is not None. */
+typedef struct rri_params {
+    int32_t fix_W;                 /* nmf.py:460 */
+    int32_t fix_T;                 /* nmf.py:417 */
+    int32_t project_T_each_iter;   /* s = t_row_sum in the T-row qf_min, nmf.py:442-447 */
+    int32_t has_t_row_sum;
+    int32_t has_w_row_sum;         /* scalar w_row_sum: the `ub` of the W-column qf_min, nmf.py:469 */
+    int32_t reset_method;          /* RRI_RESET_*; nmf.py:104 */
+    int32_t resets_left;           /* nmf.py:105,192-193: budget still available */
+    int32_t reserved0;
+    double t_row_sum;
+    double w_row_sum;
+    double reg_w_l1, reg_w_l2, reg_t_l1, reg_t_l2; /* nmf.py:106 */
+    double eps_div;                /* np.spacing(10), nmf.py:52 */
+} rri_params;
+
+typedef struct rri_event {
+    int32_t kind;    /* RRI_EVENT_* */
+    int32_t topic;   /* t */
+    int32_t sweep;   /* sweep index inside the interrupted rri_sweep call */
+    int32_t reserved;
+} rri_event;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+uint32_t   rri_abi_version(void);
+/* dtype: RRI_F32 / RRI_F64.  weighted != 0 reserves the mask and masked-residual
+ * buffers of the elementwise-weighted flavour (WRRI, nmf.py:687-701,735-746).
+ * device: HIP device ordinal.  stream: hipStream_t to run on, or NULL for an own stream. */
+rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dtype,
+                      int32_t weighted, int32_t device, void* stream);
+rri_status rri_destroy(rri_ctx* ctx);
+const char* rri_last_error(const rri_ctx* ctx);   /* NULL ctx: error of the last failed rri_create */
+
+/* ---- data: replaces the numpy arrays nmf() holds (nmf.py:272,351,867-868) --------- */
+/* host_dtype: RRI_F32 / RRI_F64 of the HOST buffer; converted to the handle's dtype. */
+rri_status rri_upload_X(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);
+rri_status rri_upload_mask(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype); /* W_mat */
+/* Zero-copy alternative: X (and mask) already in device memory in the handle's dtype,
+ * row-major with row stride ld (a multiple of 16 bytes, base 16-byte aligned). */
+rri_status rri_bind_X_device(rri_ctx* ctx, const void* dev, int64_t ld);
+rri_status rri_bind_mask_device(rri_ctx* ctx, const void* dev, int64_t ld);
+rri_status rri_set_W(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);  /* n*k */
+rri_status rri_set_T(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);  /* k*d */
+rri_status rri_get_W(rri_ctx* ctx, void* host, int64_t ld, int32_t host_dtype);
+rri_status rri_get_T(rri_ctx* ctx, void* host, int64_t ld, int32_t host_dtype);
+rri_status rri_set_params(rri_ctx* ctx, const rri_params* p);
+
+/* ---- the hot path: the topic loop of nmf.py:415-476 ----------------------------- */
+/* Runs n_sweeps Gauss-Seidel sweeps (each = k topic steps: T-row update, then W-column
+ * update).  Returns RRI_OK, RRI_PAUSED (a reset condition of nmf.py:762-783 / :796-816
+ * was met: query rri_pending_event, resolve it with rri_apply_reset_* and call
+ * rri_resume), or a negative error mirroring the reference's exceptions.
+ * sweeps_done (may be NULL) receives the number of COMPLETED sweeps of this call. */
+rri_status rri_sweep(rri_ctx* ctx, int32_t n_sweeps, int32_t* sweeps_done);
+rri_status rri_resume(rri_ctx* ctx, int32_t* sweeps_done);
+rri_status rri_pending_event(rri_ctx* ctx, rri_event* ev);
+/* 'max_resid_document' (nmf.py:770-776, :804-810), entirely on the device. */
+rri_status rri_apply_reset_max_resid(rri_ctx* ctx, int32_t t, int64_t* row_chosen);
+/* 'random' (nmf.py:778-783, :811-816): the caller draws the vectors with numpy's
+ * global RNG (as the reference does) and hands them over. */
+rri_status rri_apply_reset_vectors(rri_ctx* ctx, int32_t t, const double* T_row, const double* W_col);
+/* skip the pending reset (budget exhausted, nmf.py:765-768 / :797-800) */
+rri_status rri_skip_reset(rri_ctx* ctx);
+
+/* Finer-grained steps (tests, host drivers): one half of one topic step. */
+rri_status rri_update_T_row(rri_ctx* ctx, int32_t t);   /* nmf.py:417-458 */
+rri_status rri_update_W_col(rri_ctx* ctx, int32_t t);   /* nmf.py:460-476 */
+
+/* ---- around the loop ------------------------------------------------------------ */
+/* Row-wise simplex projection of W (proj_mat_to_simplex, matrixops.py:72-100; final
+ * projection nmf.py:519-529).  s_vec == NULL: every row to the scalar s; else n doubles. */
+rri_status rri_project_W_rows(rri_ctx* ctx, double s, const double* s_vec);
+/* true_objective (nmf.py:71-94) with the handle's regularisers and mask; float64 accumulation. */
+rri_status rri_objective(rri_ctx* ctx, double* out);
+/* argmax over topics of every row of W (harden_distributions, matrixops.py:203-209). */
+rri_status rri_argmax_rows(rri_ctx* ctx, int32_t* out_host);
+/* X*T^T clipped reconstruction error on listed entries: RMSE of NMF_RS_Estimator.score /
+ * RMSE_val (sklearn_interface.py:85-91,172-182).  idx = (i,j) pairs, vals = ratings. */
+rri_status rri_masked_rmse(rri_ctx* ctx, const int64_t* ij, const double* vals, int64_t count,
+                           double clip_lo, double clip_hi, double* out);
+/* device-side copy of (W,T) for the early-stop rollback of nmf.py:360-363,393-407 */
+rri_status rri_snapshot(rri_ctx* ctx);
+rri_status rri_rollback(rri_ctx* ctx);
+
+/* ---- row-sharded multi-GPU (one process per GPU; the caller owns the collective) ---- */
+/* A topic step splits at the one cross-row reduction it needs.  rri_topic_reduce_local
+ * leaves this rank's partial sums [w_t^T X (d) | w_t^T W (k) | ||w_t||^2 | sum W[:,t-1] | pad]
+ * in the reduce buffer; the caller all-reduces (sum) that buffer over the ranks (RCCL over
+ * xGMI via torch.distributed) and calls rri_topic_finish, which is rank-local. */
+rri_status rri_reduce_buffer(rri_ctx* ctx, void** dev_ptr, int64_t* n_elems); /* dtype = handle's */
+rri_status rri_bind_reduce_buffer(rri_ctx* ctx, void* dev_ptr, int64_t n_elems);
+rri_status rri_topic_reduce_local(rri_ctx* ctx, int32_t t);
+rri_status rri_topic_finish(rri_ctx* ctx, int32_t t);
+/* status word of the interrupted / failed step after a stream sync (same codes as rri_sweep) */
+rri_status rri_poll(rri_ctx* ctx);
+/* rank-local pieces of the objective: out[0] = 0.5*sum (Wm.)(X-WT)^2 over local rows,
+ * out[1] = sum W^2, out[2] = sum |W| (local rows); T terms are replicated. */
+rri_status rri_objective_parts(rri_ctx* ctx, double out[3]);
+
+/* ---- measurement --------------------------------------------------------------- */
+/* HIP-event timing of the streaming kernels on the handle's stream.  kernel_id:
+ * 0 = fused X pass (row dots + column sums), 1 = W-column update, 2 = T-row update chain,
+ * 3 = rank-one residual update (explicit-residual / WRRI flavour). */
+rri_status rri_timing_enable(rri_ctx* ctx, int32_t on);
+rri_status rri_timing_read(rri_ctx* ctx, int32_t kernel_id, int64_t* launches, double* total_ms);
+rri_status rri_synchronize(rri_ctx* ctx);
+/* Stand-alone kernels for roofline measurement (bench.py): R <- R - a b^T fused with the
+ * next residual products, on a scratch residual of the handle's shape. */
+rri_status rri_bench_rank1_update(rri_ctx* ctx, int32_t reps, double* avg_ms);
+rri_status rri_bench_stream_copy(rri_ctx* ctx, int32_t reps, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRI_HIP_H */

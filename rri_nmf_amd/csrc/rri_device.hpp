@@ -1,0 +1,121 @@
+// rri_device.hpp -- device-side helpers shared by the RRI kernels (gfx950 / CDNA4 only).
+//
+// Wave = 64 lanes.  Cross-lane sums use DPP modifiers (one VALU op per step, no LDS
+// crossbar traffic); workgroup sums go wave -> LDS -> wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rri {
+
+typedef long long i64;
+
+// ---- 16-byte vector of the arithmetic type ------------------------------------------
+template <typename S> struct V16;
+template <> struct V16<float> {
+    typedef float4 type;
+    static constexpr int N = 4;
+};
+template <> struct V16<double> {
+    typedef double2 type;
+    static constexpr int N = 2;
+};
+
+__device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ float vdot(const float4& a, const float4& b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+__device__ __forceinline__ double vdot(const double2& a, const double2& b, double acc) {
+    acc = fma(a.x, b.x, acc);
+    acc = fma(a.y, b.y, acc);
+    return acc;
+}
+__device__ __forceinline__ void vaxpy(float4& z, float w, const float4& x) {
+    z.x = fmaf(w, x.x, z.x);
+    z.y = fmaf(w, x.y, z.y);
+    z.z = fmaf(w, x.z, z.z);
+    z.w = fmaf(w, x.w, z.w);
+}
+__device__ __forceinline__ void vaxpy(double2& z, double w, const double2& x) {
+    z.x = fma(w, x.x, z.x);
+    z.y = fma(w, x.y, z.y);
+}
+__device__ __forceinline__ void vadd(float4& z, const float4& x) {
+    z.x += x.x; z.y += x.y; z.z += x.z; z.w += x.w;
+}
+__device__ __forceinline__ void vadd(double2& z, const double2& x) {
+    z.x += x.x; z.y += x.y;
+}
+
+// ---- DPP lane moves -------------------------------------------------------------------
+// dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141,
+//           row_bcast:15 0x142, row_bcast:31 0x143 (GFX9 wave64 forms).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(dpp_i32<CTRL, ROW_MASK>(__float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp(double v) {
+    int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
+    int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_get(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_get(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int lane_get(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// Sum over the 64 lanes of a FULLY ACTIVE wave; result returned wave-uniform.
+template <typename S>
+__device__ __forceinline__ S wave_sum(S v) {
+    v += dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row total
+    v += dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+    v += dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
+    return lane_get(v, 63);
+}
+__device__ __forceinline__ i64 wave_sum_i64(i64 v) {
+    double d = wave_sum<double>((double)v);  // counts < 2^53: exact
+    return (i64)d;
+}
+
+// max with first-index tie-break over a fully active wave (butterfly through LDS-free shuffles)
+__device__ __forceinline__ void wave_argmax(double& v, i64& idx) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(v, off, 64);
+        i64 oi = __shfl_xor(idx, off, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// Workgroup sum of doubles; every thread gets the total.  `scratch` holds >= 33 doubles.
+// All threads of the block must call (blockDim.x a multiple of 64).
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double w = wave_sum<double>(v);
+    __syncthreads();  // protect scratch from a previous use
+    if (lane == 0) scratch[wave] = w;
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < nw; ++i) tot += scratch[i];  // fixed order: deterministic
+    return tot;
+}
+
+}  // namespace rri

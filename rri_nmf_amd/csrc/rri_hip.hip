@@ -1,0 +1,1134 @@
+// rri_hip.hip -- librri_hip.so: host side of the C ABI declared in include/rri_hip.h.
+//
+// Build (see __graft_entry__.build / rri_nmf_amd/build.py):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -Iinclude rri_nmf_amd/csrc/rri_hip.hip
+//
+// Data layout in HBM (one handle = one nmf() call = one row shard of one GPU):
+//   X     n x LD   row-major, LD = d rounded up to a 16-byte multiple, pad columns zero
+//   W     n x k    row-major (as the reference); the active column is ALSO kept contiguous
+//                  in `wcol` (n) so the streaming pass reads it coalesced into LDS
+//   T     k x LD   row-major, pad columns zero
+//   Ypart npanels x n      per-column-panel partial row dots of the pass
+//   Zpart nrb x LD         per-row-block partial column sums of the pass
+//   Gpart nwb x (k+2)      per-block partial Gram row / norm / column sum (float64)
+//   red   LD + k + 2       reduced [w^T X | w^T W | ||w||^2 | sum W[:,t-1]]  (all-reduce payload)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rri_hip.h"
+#include "rri_kernels.hpp"
+
+using namespace rri;
+
+namespace {
+
+std::string g_create_error;
+
+struct Cursor {
+    int sweep, topic, phase;  // phase 0 = T-row half, 1 = W-column half
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rri_ctx {
+    i64 n = 0, d = 0, LD = 0;
+    int k = 0, dtype = RRI_F32, weighted = 0, device = 0;
+    size_t es = 4;
+    int VN = 4, PW = 1024;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    void *X = nullptr, *M = nullptr, *E = nullptr;
+    i64 ldx = 0, ldm = 0;
+    bool own_X = false, own_M = false;
+    void *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
+    void *wcol = nullptr, *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Tt = nullptr;
+    bool own_red = false;
+    i64 red_elems = 0;
+    double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
+    double *dtmp = nullptr;  // small double scratch (device): [0] sum, ...
+    i64* itmp = nullptr;     // small i64 scratch (device)
+    i64* tpart_idx = nullptr;
+    double *resetT = nullptr, *resetW = nullptr;  // staging for 'random' reset vectors
+    DevState* st = nullptr;
+
+    int npanels = 1, rpb = 1, nrb = 1, RW = 256, nwb = 1, ntb = 1;
+    size_t wcol_shmem = 0;
+
+    rri_params prm{};
+    bool have_params = false, have_X = false, have_W = false, have_T = false, have_M = false;
+
+    bool carry_valid = false;
+    int carry_topic = -1;
+    bool pending_wcheck = false;
+    int pending_wcheck_topic = -1;
+
+    // interrupted run
+    bool paused = false;
+    int run_total = 0;
+    Cursor resume_at{0, 0, 0};
+    bool resume_done = false;
+    rri_event pending{RRI_EVENT_NONE, -1, 0, 0};
+
+    bool resid_valid = false;  // masked residual E is in sync with (W,T) (weighted flavour)
+
+    bool timing = false;
+    std::vector<TimedLaunch> timed[4];
+    std::vector<hipEvent_t> event_pool;
+
+    std::string err;
+};
+
+namespace {
+
+rri_status fail(rri_ctx* c, rri_status code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), RRI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define CHECK_CTX(c) \
+    if (!(c)) return RRI_ERR_INVALID
+
+i64 round_up(i64 a, i64 b) { return (a + b - 1) / b * b; }
+
+KParams kparams(const rri_ctx* c) {
+    KParams p{};
+    const rri_params& q = c->prm;
+    p.fix_W = q.fix_W; p.fix_T = q.fix_T; p.project_T = q.project_T_each_iter;
+    p.has_trs = q.has_t_row_sum; p.has_wrs = q.has_w_row_sum;
+    p.reset_method = q.reset_method; p.resets_left = q.resets_left;
+    p.t_row_sum = q.t_row_sum; p.w_row_sum = q.w_row_sum;
+    p.reg_w_l1 = q.reg_w_l1; p.reg_w_l2 = q.reg_w_l2; p.reg_t_l1 = q.reg_t_l1; p.reg_t_l2 = q.reg_t_l2;
+    p.eps = q.eps_div;
+    return p;
+}
+
+bool no_regs(const rri_ctx* c) {
+    const rri_params& q = c->prm;
+    return std::abs(q.reg_w_l1) + std::abs(q.reg_w_l2) + std::abs(q.reg_t_l1) + std::abs(q.reg_t_l2) == 0.0;
+}
+
+// ---- timing ------------------------------------------------------------------------------
+hipEvent_t get_event(rri_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct TimedScope {
+    rri_ctx* c;
+    int id;
+    TimedLaunch tl{nullptr, nullptr};
+    bool on;
+    TimedScope(rri_ctx* c_, int id_) : c(c_), id(id_), on(c_->timing && c_->timed[id_].size() < 400000) {
+        if (on) {
+            tl.a = get_event(c);
+            tl.b = get_event(c);
+            (void)hipEventRecord(tl.a, c->stream);
+        }
+    }
+    ~TimedScope() {
+        if (on) {
+            (void)hipEventRecord(tl.b, c->stream);
+            c->timed[id].push_back(tl);
+        }
+    }
+};
+
+// ---- typed launch helpers ------------------------------------------------------------------
+template <typename S>
+struct Launch {
+    static size_t pass_shmem(const rri_ctx* c) { return 4 * 4 * 64 * 16 + 2 * (size_t)c->rpb * sizeof(S); }
+
+    template <bool DO_Y, bool DO_Z>
+    static void pass(rri_ctx* c, int t) {
+        TimedScope ts(c, 0);
+        const S* trow = (const S*)c->T + (i64)t * c->LD;
+        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        hipLaunchKernelGGL((k_pass<S, DO_Y, DO_Z, false>), dim3(c->npanels * c->nrb), dim3(256), pass_shmem(c),
+                           c->stream, (const S*)c->X, c->ldx, (int)c->n, ncols, trow, (const S*)c->wcol,
+                           (S*)c->Ypart, (S*)c->Zpart, c->LD, c->rpb, c->npanels, (const S*)nullptr,
+                           (const S*)nullptr, (const DevState*)c->st);
+    }
+    // R <- R - a b^T fused with the row dots (against trow) and column sums (against wcol) of the new R
+    static void rank1(rri_ctx* c, void* R, const void* a, const void* b, const void* trow, const void* wc) {
+        TimedScope ts(c, 3);
+        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        hipLaunchKernelGGL((k_pass<S, true, true, true>), dim3(c->npanels * c->nrb), dim3(256), pass_shmem(c),
+                           c->stream, (S*)R, c->ldx, (int)c->n, ncols, (const S*)trow, (const S*)wc, (S*)c->Ypart,
+                           (S*)c->Zpart, c->LD, c->rpb, c->npanels, (const S*)a, (const S*)b,
+                           (const DevState*)c->st);
+    }
+    template <bool UPDATE, bool CARRY>
+    static void wcol(rri_ctx* c, int t, int tn, int tx, int sweep) {
+        TimedScope ts(c, 1);
+        hipLaunchKernelGGL((k_wcol<S, UPDATE, CARRY>), dim3(c->nwb), dim3(c->RW), c->wcol_shmem, c->stream,
+                           (S*)c->W, (int)c->n, c->k, t, tn, tx, (const S*)c->Ypart, c->npanels, (const S*)c->Tt,
+                           (S*)c->wcol, c->Gpart, sweep, kparams(c), c->st);
+    }
+    static void extract_col(rri_ctx* c, int col) {
+        hipLaunchKernelGGL((k_extract_col<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const S*)c->W, (int)c->n, c->k, col, (S*)c->wcol, (const DevState*)c->st);
+    }
+    static void reduce(rri_ctx* c) {
+        const int nb = (int)((c->LD + 255) / 256) + 1;
+        hipLaunchKernelGGL((k_reduce<S>), dim3(nb), dim3(256), 0, c->stream, (const S*)c->Zpart, c->LD, c->nrb,
+                           (const double*)c->Gpart, c->nwb, c->k, (S*)c->red, (const DevState*)c->st);
+    }
+    static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep) {
+        hipLaunchKernelGGL((k_trow_numer<S>), dim3(c->ntb), dim3(256), 0, c->stream, (const S*)c->T, c->LD,
+                           (int)c->d, c->k, t, (const S*)c->red, c->LD, (S*)c->xraw, c->tpart, c->tpart_idx,
+                           check_prev, tprev, sweep, kparams(c), c->st);
+        hipLaunchKernelGGL((k_trow_final<S>), dim3(1), dim3(1024), 0, c->stream, (S*)c->T, c->LD, (int)c->d, t,
+                           (S*)c->xraw, (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep,
+                           kparams(c), c->st);
+    }
+    static void check_prev_only(rri_ctx* c, int tprev, int sweep, int pos) {
+        hipLaunchKernelGGL((k_check_red<S>), dim3(1), dim3(64), 0, c->stream, (const S*)c->red, c->LD, c->k, tprev,
+                           sweep, pos, kparams(c), c->st);
+    }
+    static void tgram(rri_ctx* c, int t) {
+        hipLaunchKernelGGL((k_tgram<S>), dim3(c->k), dim3(256), 0, c->stream, (const S*)c->T, c->LD, (int)c->d, t,
+                           (S*)c->Tt, c->st);
+    }
+    static void scale_wcol(rri_ctx* c, int t) {
+        hipLaunchKernelGGL((k_scale_wcol<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                           (S*)c->W, (int)c->n, c->k, t, (const DevState*)c->st);
+    }
+    static void check_wcol(rri_ctx* c, int tprev, int sweep, int pos) {
+        hipLaunchKernelGGL((k_check_wcol<S>), dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb,
+                           c->k, tprev, sweep, pos, kparams(c), c->st);
+    }
+    static void proj_rows(rri_ctx* c, double s, const double* svec) {
+        const size_t sh = (size_t)c->RW * (c->k + 1) * sizeof(S);
+        hipLaunchKernelGGL((k_proj_rows<S>), dim3(c->nwb), dim3(c->RW), sh, c->stream, (S*)c->W, (int)c->n, c->k,
+                           s, svec);
+    }
+    static size_t resid_shmem(const rri_ctx* c) {
+        return ((size_t)c->k * 64 + 32 * 64) * sizeof(S) + 64 * 17 * sizeof(double);
+    }
+    static void resid(rri_ctx* c, bool masked, bool write_e, double* rowobj, double* rowpos) {
+        const unsigned nb = (unsigned)((c->n + 63) / 64);
+        const size_t sh = resid_shmem(c);
+#define RRI_RESID(MK, WE)                                                                                       \
+    hipLaunchKernelGGL((k_resid<S, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const S*)c->X, c->ldx,       \
+                       (const S*)c->M, c->ldm, (const S*)c->W, (const S*)c->T, c->LD, (int)c->n, (int)c->d,     \
+                       c->k, rowobj, rowpos, (S*)c->E, c->LD)
+        if (masked && write_e) RRI_RESID(true, true);
+        else if (masked) RRI_RESID(true, false);
+        else if (write_e) RRI_RESID(false, true);
+        else RRI_RESID(false, false);
+#undef RRI_RESID
+    }
+    static void norms(rri_ctx* c, const void* A, i64 rows, i64 cols, i64 ld) {
+        hipLaunchKernelGGL((k_norms<S>), dim3(256), dim3(256), 0, c->stream, (const S*)A, rows, cols, ld,
+                           c->normpart);
+    }
+    static void reset_row(rri_ctx* c, int t) {
+        hipLaunchKernelGGL((k_reset_row<S>), dim3(c->ntb), dim3(256), 0, c->stream, (const S*)c->X, c->ldx,
+                           (const S*)c->W, (const S*)c->T, c->LD, (int)c->d, c->k, (const i64*)c->itmp,
+                           (S*)c->xraw);
+        const i64 m = std::max(c->n, c->d);
+        hipLaunchKernelGGL((k_reset_commit<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                           (S*)c->W, (S*)c->T, c->LD, (int)c->n, (int)c->d, c->k, t, (const i64*)c->itmp,
+                           (const S*)c->xraw);
+    }
+    static void set_row_col(rri_ctx* c, int t, const double* trow, const double* wcolv) {
+        const i64 m = std::max(c->n, c->d);
+        hipLaunchKernelGGL((k_set_row_col<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                           (S*)c->W, (S*)c->T, c->LD, (int)c->n, (int)c->d, c->k, t, trow, wcolv);
+    }
+    static void argmax_rows(rri_ctx* c, int* out) {
+        hipLaunchKernelGGL((k_argmax_rows<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const S*)c->W, (int)c->n, c->k, out);
+    }
+    static void masked_sqerr(rri_ctx* c, const i64* ij, const double* vals, i64 count, double lo, double hi) {
+        hipLaunchKernelGGL((k_masked_sqerr<S>), dim3(256), dim3(256), 0, c->stream, (const S*)c->W,
+                           (const S*)c->T, c->LD, c->k, ij, vals, count, lo, hi, c->normpart);
+    }
+};
+
+#define DISPATCH(c, expr)                       \
+    do {                                        \
+        if ((c)->dtype == RRI_F32) {            \
+            typedef Launch<float> L;            \
+            expr;                               \
+        } else {                                \
+            typedef Launch<double> L;           \
+            expr;                               \
+        }                                       \
+    } while (0)
+
+// ---- upload / download with conversion -------------------------------------------------------
+template <typename Src, typename Dst>
+void launch_convert(rri_ctx* c, const void* src, i64 lds_, void* dst, i64 ldd, i64 rows, i64 cols) {
+    const i64 total = rows * cols;
+    const unsigned nb = (unsigned)std::min<i64>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL((k_convert2d<Src, Dst>), dim3(nb ? nb : 1), dim3(256), 0, c->stream, (const Src*)src, lds_,
+                       (Dst*)dst, ldd, rows, cols);
+}
+
+// host (rows x cols, stride ld, host_dtype) -> device (stride ldd, handle dtype)
+rri_status to_device(rri_ctx* c, const void* host, i64 ld, int host_dtype, void* dev, i64 ldd, i64 rows,
+                     i64 cols) {
+    if (!host || ld < cols) return fail(c, RRI_ERR_INVALID, "bad host matrix (ld=%lld < cols=%lld)", ld, cols);
+    const size_t hs = host_dtype == RRI_F32 ? 4 : 8;
+    if (host_dtype == c->dtype) {
+        HIPCHK(c, hipMemcpy2DAsync(dev, ldd * c->es, host, ld * hs, cols * hs, rows, hipMemcpyHostToDevice,
+                                   c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return RRI_OK;
+    }
+    void* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, (size_t)rows * cols * hs));
+    hipError_t e = hipMemcpy2DAsync(tmp, cols * hs, host, ld * hs, cols * hs, rows, hipMemcpyHostToDevice,
+                                    c->stream);
+    if (e == hipSuccess) {
+        if (host_dtype == RRI_F32) launch_convert<float, double>(c, tmp, cols, dev, ldd, rows, cols);
+        else launch_convert<double, float>(c, tmp, cols, dev, ldd, rows, cols);
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    return RRI_OK;
+}
+
+rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int host_dtype, i64 rows, i64 cols) {
+    if (!host || ld < cols) return fail(c, RRI_ERR_INVALID, "bad host matrix (ld=%lld < cols=%lld)", ld, cols);
+    const size_t hs = host_dtype == RRI_F32 ? 4 : 8;
+    if (host_dtype == c->dtype) {
+        HIPCHK(c, hipMemcpy2DAsync(host, ld * hs, dev, ldd * c->es, cols * hs, rows, hipMemcpyDeviceToHost,
+                                   c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return RRI_OK;
+    }
+    void* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, (size_t)rows * cols * hs));
+    if (host_dtype == RRI_F32) launch_convert<double, float>(c, dev, ldd, tmp, cols, rows, cols);
+    else launch_convert<float, double>(c, dev, ldd, tmp, cols, rows, cols);
+    hipError_t e = hipMemcpy2DAsync(host, ld * hs, tmp, cols * hs, cols * hs, rows, hipMemcpyDeviceToHost,
+                                    c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+    return RRI_OK;
+}
+
+void invalidate(rri_ctx* c) {
+    c->carry_valid = false;
+    c->carry_topic = -1;
+    c->resid_valid = false;
+}
+
+// ---- the topic-step scheduler ------------------------------------------------------------------
+// carry := Zpart/Gpart hold the partial sums of topic `carry_topic` AND wcol holds column carry_topic+1.
+void enqueue_prologue(rri_ctx* c, int t, int sweep) {
+    // the pending W-column check reads Gpart, which the prologue overwrites: resolve it first
+    if (c->pending_wcheck) {
+        DISPATCH(c, L::check_wcol(c, c->pending_wcheck_topic, sweep, t));
+        c->pending_wcheck = false;
+    }
+    DISPATCH(c, (L::template wcol<false, true>(c, t, t, t, sweep)));   // Gram row of w_t, wcol = W[:,t]
+    DISPATCH(c, (L::template pass<false, true>(c, t)));               // w_t^T X
+    if (c->k > 1) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));     // next pass needs W[:,t+1]
+    c->carry_valid = true;
+    c->carry_topic = t;
+}
+
+void enqueue_T_half(rri_ctx* c, int sweep, int t) {
+    if (!c->carry_valid || c->carry_topic != t) enqueue_prologue(c, t, sweep);
+    {
+        TimedScope ts(c, 2);
+        DISPATCH(c, L::reduce(c));
+        const int chk = c->pending_wcheck ? 1 : 0;
+        DISPATCH(c, L::trow(c, t, chk, c->pending_wcheck_topic, sweep));
+        c->pending_wcheck = false;
+        if (c->prm.fix_W && no_regs(c)) DISPATCH(c, L::scale_wcol(c, t));
+    }
+    c->carry_valid = false;
+    c->resid_valid = false;
+}
+
+void enqueue_W_half(rri_ctx* c, int sweep, int t) {
+    const int k = c->k;
+    const bool carry_next = (k > 1) && !c->prm.fix_T;
+    const int tn = (t + 1) % k, tx = (t + 2) % k;
+    {
+        TimedScope ts(c, 2);
+        DISPATCH(c, L::tgram(c, t));
+    }
+    if (carry_next) {
+        DISPATCH(c, (L::template pass<true, true>(c, t)));
+        DISPATCH(c, (L::template wcol<true, true>(c, t, tn, tx, sweep)));
+        c->carry_valid = true;
+        c->carry_topic = tn;
+        c->pending_wcheck = true;
+        c->pending_wcheck_topic = t;
+    } else {
+        DISPATCH(c, (L::template pass<true, false>(c, t)));
+        DISPATCH(c, (L::template wcol<true, false>(c, t, tn, tx, sweep)));
+        // position of the NEXT step, where a resumed run continues
+        int ns = sweep, np = t + 1;
+        if (np == k) { np = 0; ns = sweep + 1; }
+        DISPATCH(c, L::check_wcol(c, t, ns, np));
+        c->carry_valid = false;
+    }
+    c->resid_valid = false;
+}
+
+void enqueue_from(rri_ctx* c, Cursor cur) {
+    const int k = c->k;
+    for (int s = cur.sweep; s < c->run_total; ++s) {
+        const int t0 = (s == cur.sweep) ? cur.topic : 0;
+        for (int t = t0; t < k; ++t) {
+            const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
+            if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, s, t);
+            if (!c->prm.fix_W) enqueue_W_half(c, s, t);
+        }
+    }
+    if (c->pending_wcheck) {  // last column of the call: report it in this call
+        DISPATCH(c, L::check_wcol(c, c->pending_wcheck_topic, c->run_total, 0));
+        c->pending_wcheck = false;
+    }
+}
+
+rri_status read_state(rri_ctx* c, DevState* out) {
+    HIPCHK(c, hipMemcpyAsync(out, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
+rri_status status_from_halt(rri_ctx* c, const DevState& s, int32_t* sweeps_done) {
+    if (s.halt == 0) {
+        c->paused = false;
+        if (sweeps_done) *sweeps_done = c->run_total;
+        return RRI_OK;
+    }
+    invalidate(c);
+    c->pending_wcheck = false;
+    if (s.halt > 0) {
+        c->paused = true;
+        c->pending.kind = s.halt == HALT_EVENT_RESET_T ? RRI_EVENT_RESET_T : RRI_EVENT_RESET_W;
+        c->pending.topic = s.halt_topic;
+        c->pending.sweep = s.halt_sweep;
+        if (s.halt == HALT_EVENT_RESET_T) c->resume_at = Cursor{s.halt_sweep, s.halt_topic, 1};
+        else c->resume_at = Cursor{s.halt_sweep, s.halt_pos, 0};
+        if (sweeps_done) *sweeps_done = s.halt_sweep;
+        return RRI_PAUSED;
+    }
+    c->paused = false;
+    if (sweeps_done) *sweeps_done = s.halt_sweep;
+    switch (s.halt) {
+        case HALT_ERR_UNBOUNDED:
+            return fail(c, RRI_ERR_UNBOUNDED, "Minimum objective is unbounded (topic %d)", s.halt_topic);
+        case HALT_ERR_W_COL_ZERO:
+            return fail(c, RRI_ERR_W_COL_ZERO, "W[:, t] sums to 0 (topic %d)", s.halt_topic);
+        case HALT_ERR_NOT_IMPLEMENTED:
+            return fail(c, RRI_ERR_NOT_IMPLEMENTED, "s=%g is not yet implemented", c->prm.t_row_sum);
+        default:
+            return fail(c, RRI_ERR_INVALID, "unknown device status %d", s.halt);
+    }
+}
+
+rri_status clear_halt(rri_ctx* c) {
+    HIPCHK(c, hipMemsetAsync(c->st, 0, 16, c->stream));  // halt, halt_topic, halt_sweep, halt_pos
+    return RRI_OK;
+}
+
+rri_status ready(rri_ctx* c) {
+    if (!c->have_X || !c->have_W || !c->have_T || !c->have_params)
+        return fail(c, RRI_ERR_INVALID, "X, W, T and params must be set before stepping");
+    if (c->weighted && !c->have_M) return fail(c, RRI_ERR_INVALID, "weighted handle without a mask");
+    return RRI_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+uint32_t rri_abi_version(void) { return RRI_ABI_VERSION; }
+
+const char* rri_last_error(const rri_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dtype, int32_t weighted,
+                      int32_t device, void* stream) {
+    if (!out) return RRI_ERR_INVALID;
+    *out = nullptr;
+    if (n < 1 || d < 1 || k < 1) return fail(nullptr, RRI_ERR_INVALID, "need n,d,k >= 1 (got %lld,%lld,%d)", n, d, k);
+    if (dtype != RRI_F32 && dtype != RRI_F64) return fail(nullptr, RRI_ERR_INVALID, "dtype must be RRI_F32/RRI_F64");
+    if (n > 2000000000LL || d > 2000000000LL) return fail(nullptr, RRI_ERR_INVALID, "n, d must fit int32");
+    if (k > 256) return fail(nullptr, RRI_ERR_UNSUPPORTED, "k=%d > 256 not supported on the device path", k);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, RRI_ERR_HIP, "no HIP device available (librri_hip needs an MI355X)");
+    if (device < 0 || device >= ndev) return fail(nullptr, RRI_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    rri_ctx* c = new rri_ctx();
+    c->n = n; c->d = d; c->k = k; c->dtype = dtype; c->weighted = weighted; c->device = device;
+    c->es = dtype == RRI_F32 ? 4 : 8;
+    c->VN = (int)(16 / c->es);
+    c->PW = 64 * c->VN * 4;
+    c->LD = round_up(d, c->VN);
+#define CR(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fail(nullptr, RRI_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));             \
+            rri_destroy(c);                                                                        \
+            return RRI_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+    CR(hipSetDevice(device));
+    if (stream) c->stream = (hipStream_t)stream;
+    else { CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+
+    // geometry of the streaming pass
+    c->npanels = (int)((c->LD + c->PW - 1) / c->PW);
+    int target = 1024;
+    if (const char* e = getenv("RRI_PASS_WGS")) target = std::max(1, atoi(e));
+    int nrb_t = std::max(1, target / c->npanels);
+    i64 rpb = (n + nrb_t - 1) / nrb_t;
+    int rpb_min = 32;
+    if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
+    rpb = std::max<i64>(rpb, rpb_min);
+    rpb = std::min<i64>(round_up(rpb, 16), 2048);
+    c->rpb = (int)rpb;
+    c->nrb = (int)((n + rpb - 1) / rpb);
+    // W-column kernel tile
+    c->RW = 0;
+    for (int rw : {256, 128, 64}) {
+        size_t sh = (40 + 4 * (size_t)k) * 8 + ((size_t)k + rw + (size_t)rw * (k + 1)) * c->es;
+        if (sh <= 64 * 1024 || rw == 64) { c->RW = rw; c->wcol_shmem = sh; break; }
+    }
+    if (c->wcol_shmem > 160 * 1024) {
+        fail(nullptr, RRI_ERR_UNSUPPORTED, "k=%d needs more LDS than one CU has", k);
+        rri_destroy(c);
+        return RRI_ERR_UNSUPPORTED;
+    }
+    c->nwb = (int)((n + c->RW - 1) / c->RW);
+    c->ntb = (int)((d + 255) / 256);
+    c->red_elems = round_up(c->LD + k + 2, 4);
+
+    const size_t es = c->es;
+    CR(hipMalloc(&c->W, (size_t)n * k * es));
+    CR(hipMalloc(&c->T, (size_t)k * c->LD * es));
+    CR(hipMemsetAsync(c->T, 0, (size_t)k * c->LD * es, c->stream));
+    CR(hipMalloc(&c->wcol, (size_t)n * es));
+    CR(hipMalloc(&c->Ypart, (size_t)c->npanels * n * es));
+    CR(hipMalloc(&c->Zpart, (size_t)c->nrb * c->LD * es));
+    CR(hipMalloc((void**)&c->Gpart, (size_t)c->nwb * (k + 2) * sizeof(double)));
+    CR(hipMalloc(&c->red, (size_t)c->red_elems * es));
+    CR(hipMemsetAsync(c->red, 0, (size_t)c->red_elems * es, c->stream));
+    c->own_red = true;
+    CR(hipMalloc(&c->xraw, (size_t)c->LD * es));
+    CR(hipMalloc(&c->Tt, (size_t)k * es));
+    CR(hipMalloc((void**)&c->tpart, (size_t)c->ntb * sizeof(double)));
+    CR(hipMalloc((void**)&c->tpart_idx, (size_t)c->ntb * sizeof(i64)));
+    CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
+    CR(hipMalloc((void**)&c->dtmp, 16 * sizeof(double)));
+    CR(hipMalloc((void**)&c->itmp, 16 * sizeof(i64)));
+    CR(hipMalloc((void**)&c->st, sizeof(DevState)));
+    CR(hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream));
+    // opt in to large dynamic LDS where a kernel needs it
+    if (dtype == RRI_F32) {
+        CR(hipFuncSetAttribute((const void*)k_wcol<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CR(hipFuncSetAttribute((const void*)k_wcol<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CR(hipFuncSetAttribute((const void*)k_wcol<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CR(hipFuncSetAttribute((const void*)k_proj_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    } else {
+        CR(hipFuncSetAttribute((const void*)k_wcol<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CR(hipFuncSetAttribute((const void*)k_wcol<double, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CR(hipFuncSetAttribute((const void*)k_wcol<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CR(hipFuncSetAttribute((const void*)k_proj_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    CR(hipStreamSynchronize(c->stream));
+#undef CR
+    *out = c;
+    return RRI_OK;
+}
+
+rri_status rri_destroy(rri_ctx* c) {
+    if (!c) return RRI_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_X) (void)hipFree(c->X);
+    if (c->own_M) (void)hipFree(c->M);
+    void* bufs[] = {c->E, c->W, c->T, c->Wprev, c->Tprev, c->wcol, c->Ypart, c->Zpart, c->xraw, c->Tt,
+                    c->Gpart, c->tpart, c->tpart_idx, c->rowobj, c->rowpos, c->normpart, c->dtmp, c->itmp,
+                    c->resetT, c->resetW, c->st};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->own_red && c->red) (void)hipFree(c->red);
+    for (int i = 0; i < 4; ++i)
+        for (auto& tl : c->timed[i]) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RRI_OK;
+}
+
+// ---- data ------------------------------------------------------------------------------------------
+rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->X && !c->own_X) c->X = nullptr;
+    if (!c->X) {
+        HIPCHK(c, hipMalloc(&c->X, (size_t)c->n * c->LD * c->es));
+        c->own_X = true;
+        if (c->LD != c->d) HIPCHK(c, hipMemsetAsync(c->X, 0, (size_t)c->n * c->LD * c->es, c->stream));
+    }
+    c->ldx = c->LD;
+    rri_status s = to_device(c, host, ld, host_dtype, c->X, c->ldx, c->n, c->d);
+    if (s == RRI_OK) { c->have_X = true; invalidate(c); }
+    return s;
+}
+
+rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->M && !c->own_M) c->M = nullptr;
+    if (!c->M) {
+        HIPCHK(c, hipMalloc(&c->M, (size_t)c->n * c->LD * c->es));
+        c->own_M = true;
+        if (c->LD != c->d) HIPCHK(c, hipMemsetAsync(c->M, 0, (size_t)c->n * c->LD * c->es, c->stream));
+    }
+    c->ldm = c->LD;
+    rri_status s = to_device(c, host, ld, host_dtype, c->M, c->ldm, c->n, c->d);
+    if (s == RRI_OK) { c->have_M = true; invalidate(c); }
+    return s;
+}
+
+rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
+    CHECK_CTX(c);
+    if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
+        return fail(c, RRI_ERR_INVALID, "device X must be 16-byte aligned with a 16-byte-multiple row stride >= d");
+    if (c->d % c->VN) return fail(c, RRI_ERR_INVALID, "binding device X needs d %% %d == 0 (no pad columns)", c->VN);
+    if (c->X && c->own_X) (void)hipFree(c->X);
+    c->X = const_cast<void*>(dev);
+    c->own_X = false;
+    c->ldx = ld;
+    c->have_X = true;
+    invalidate(c);
+    return RRI_OK;
+}
+
+rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
+    CHECK_CTX(c);
+    if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
+    if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
+        return fail(c, RRI_ERR_INVALID, "device mask must be 16-byte aligned with a 16-byte-multiple row stride >= d");
+    if (c->d % c->VN) return fail(c, RRI_ERR_INVALID, "binding a device mask needs d %% %d == 0", c->VN);
+    if (c->M && c->own_M) (void)hipFree(c->M);
+    c->M = const_cast<void*>(dev);
+    c->own_M = false;
+    c->ldm = ld;
+    c->have_M = true;
+    invalidate(c);
+    return RRI_OK;
+}
+
+rri_status rri_set_W(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    rri_status s = to_device(c, host, ld, host_dtype, c->W, c->k, c->n, c->k);
+    if (s == RRI_OK) { c->have_W = true; invalidate(c); c->pending_wcheck = false; }
+    return s;
+}
+rri_status rri_set_T(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    rri_status s = to_device(c, host, ld, host_dtype, c->T, c->LD, c->k, c->d);
+    if (s == RRI_OK) { c->have_T = true; invalidate(c); }
+    return s;
+}
+rri_status rri_get_W(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    return to_host(c, c->W, c->k, host, ld, host_dtype, c->n, c->k);
+}
+rri_status rri_get_T(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    return to_host(c, c->T, c->LD, host, ld, host_dtype, c->k, c->d);
+}
+
+rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
+    CHECK_CTX(c);
+    if (!p) return fail(c, RRI_ERR_INVALID, "params is NULL");
+    if (p->has_t_row_sum && !(p->t_row_sum > 0)) return fail(c, RRI_ERR_INVALID, "t_row_sum must be > 0");
+    if (p->has_w_row_sum && !(p->w_row_sum > 0)) return fail(c, RRI_ERR_INVALID, "w_row_sum must be > 0");
+    if (p->reset_method < 0 || p->reset_method > 2) return fail(c, RRI_ERR_INVALID, "bad reset_method");
+    if (p->fix_W && p->fix_T) return fail(c, RRI_ERR_INVALID, "fix_W and fix_T together leave nothing to update");
+    c->prm = *p;
+    c->have_params = true;
+    return RRI_OK;
+}
+
+// ---- the hot path ------------------------------------------------------------------------------------
+static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done) {
+    HIPCHK(c, hipSetDevice(c->device));
+    enqueue_from(c, from);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(c, RRI_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+    DevState s;
+    rri_status r = read_state(c, &s);
+    if (r != RRI_OK) return r;
+    return status_from_halt(c, s, sweeps_done);
+}
+
+rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
+    CHECK_CTX(c);
+    rri_status r = ready(c);
+    if (r != RRI_OK) return r;
+    if (c->weighted) return fail(c, RRI_ERR_UNSUPPORTED, "use the weighted sweep entry (rri_sweep on a weighted handle is routed in rri_wrri.hpp)");
+    if (c->paused) return fail(c, RRI_ERR_INVALID, "a paused run is pending: resolve the event and call rri_resume");
+    if (n_sweeps < 0) return fail(c, RRI_ERR_INVALID, "n_sweeps < 0");
+    c->run_total = n_sweeps;
+    r = clear_halt(c);
+    if (r != RRI_OK) return r;
+    return run_and_collect(c, Cursor{0, 0, 0}, sweeps_done);
+}
+
+rri_status rri_resume(rri_ctx* c, int32_t* sweeps_done) {
+    CHECK_CTX(c);
+    if (!c->paused) return fail(c, RRI_ERR_INVALID, "nothing to resume");
+    if (c->pending.kind != RRI_EVENT_NONE) return fail(c, RRI_ERR_INVALID, "pending event not resolved");
+    c->paused = false;
+    rri_status r = clear_halt(c);
+    if (r != RRI_OK) return r;
+    return run_and_collect(c, c->resume_at, sweeps_done);
+}
+
+rri_status rri_pending_event(rri_ctx* c, rri_event* ev) {
+    CHECK_CTX(c);
+    if (!ev) return fail(c, RRI_ERR_INVALID, "ev is NULL");
+    *ev = c->paused ? c->pending : rri_event{RRI_EVENT_NONE, -1, 0, 0};
+    return RRI_OK;
+}
+
+static void event_resolved(rri_ctx* c) {
+    c->pending.kind = RRI_EVENT_NONE;
+    if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
+    invalidate(c);
+    if (c->resume_at.phase == 1) {
+        // resuming at the W half of topic t: the pass needs wcol = W[:,t+1] (untouched by the reset of column t)
+    }
+}
+
+rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen) {
+    CHECK_CTX(c);
+    if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->rowpos) HIPCHK(c, hipMalloc((void**)&c->rowpos, (size_t)c->n * sizeof(double)));
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    DISPATCH(c, L::resid(c, false, false, nullptr, c->rowpos));
+    hipLaunchKernelGGL(k_vec_sum_argmax, dim3(1), dim3(1024), 0, c->stream, (const double*)c->rowpos, c->n,
+                       (double*)nullptr, c->itmp);
+    DISPATCH(c, L::reset_row(c, t));
+    i64 mi = -1;
+    HIPCHK(c, hipMemcpyAsync(&mi, c->itmp, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (row_chosen) *row_chosen = mi;
+    if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
+    else invalidate(c);
+    // a resumed W half needs the next active column in wcol
+    if (c->k > 1) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));
+    return RRI_OK;
+}
+
+rri_status rri_apply_reset_vectors(rri_ctx* c, int32_t t, const double* T_row, const double* W_col) {
+    CHECK_CTX(c);
+    if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resetT) HIPCHK(c, hipMalloc((void**)&c->resetT, (size_t)c->d * sizeof(double)));
+    if (!c->resetW) HIPCHK(c, hipMalloc((void**)&c->resetW, (size_t)c->n * sizeof(double)));
+    if (T_row) HIPCHK(c, hipMemcpyAsync(c->resetT, T_row, (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (W_col) HIPCHK(c, hipMemcpyAsync(c->resetW, W_col, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DISPATCH(c, L::set_row_col(c, t, T_row ? c->resetT : nullptr, W_col ? c->resetW : nullptr));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
+    else invalidate(c);
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    if (c->k > 1) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));
+    return RRI_OK;
+}
+
+rri_status rri_skip_reset(rri_ctx* c) {
+    CHECK_CTX(c);
+    if (!c->paused) return fail(c, RRI_ERR_INVALID, "no pending event");
+    c->pending.kind = RRI_EVENT_NONE;
+    c->prm.resets_left = 0;
+    return RRI_OK;
+}
+
+rri_status rri_update_T_row(rri_ctx* c, int32_t t) {
+    CHECK_CTX(c);
+    rri_status r = ready(c);
+    if (r != RRI_OK) return r;
+    if (c->weighted) return fail(c, RRI_ERR_UNSUPPORTED, "half steps are not exposed for the weighted flavour");
+    if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->run_total = 1;
+    r = clear_halt(c);
+    if (r != RRI_OK) return r;
+    enqueue_T_half(c, 0, t);
+    DevState s;
+    r = read_state(c, &s);
+    if (r != RRI_OK) return r;
+    return status_from_halt(c, s, nullptr);
+}
+
+rri_status rri_update_W_col(rri_ctx* c, int32_t t) {
+    CHECK_CTX(c);
+    rri_status r = ready(c);
+    if (r != RRI_OK) return r;
+    if (c->weighted) return fail(c, RRI_ERR_UNSUPPORTED, "half steps are not exposed for the weighted flavour");
+    if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->run_total = 1;
+    r = clear_halt(c);
+    if (r != RRI_OK) return r;
+    // the half step must not depend on what an earlier call left in wcol
+    if (c->k > 1 && !c->prm.fix_T) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));
+    enqueue_W_half(c, 0, t);
+    if (c->pending_wcheck) {
+        DISPATCH(c, L::check_wcol(c, c->pending_wcheck_topic, 1, 0));
+        c->pending_wcheck = false;
+    }
+    DevState s;
+    r = read_state(c, &s);
+    if (r != RRI_OK) return r;
+    return status_from_halt(c, s, nullptr);
+}
+
+// ---- around the loop ------------------------------------------------------------------------------------
+rri_status rri_project_W_rows(rri_ctx* c, double s, const double* s_vec) {
+    CHECK_CTX(c);
+    if (!c->have_W) return fail(c, RRI_ERR_INVALID, "W not set");
+    if (!s_vec && !(s > 0)) return fail(c, RRI_ERR_INVALID, "Radius s must be strictly positive");
+    HIPCHK(c, hipSetDevice(c->device));
+    double* dvec = nullptr;
+    if (s_vec) {
+        HIPCHK(c, hipMalloc((void**)&dvec, (size_t)c->n * sizeof(double)));
+        HIPCHK(c, hipMemcpyAsync(dvec, s_vec, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    DISPATCH(c, L::proj_rows(c, s, dvec));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (dvec) (void)hipFree(dvec);
+    invalidate(c);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "projection failed: %s", hipGetErrorString(e));
+    return RRI_OK;
+}
+
+static rri_status norms_of(rri_ctx* c, const void* A, i64 rows, i64 cols, i64 ld, double out[3]) {
+    DISPATCH(c, L::norms(c, A, rows, cols, ld));
+    double h[256 * 3];
+    HIPCHK(c, hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out[0] = out[1] = out[2] = 0.0;
+    for (int b = 0; b < 256; ++b) { out[0] += h[3 * b]; out[1] += h[3 * b + 1]; out[2] += h[3 * b + 2]; }
+    return RRI_OK;
+}
+
+rri_status rri_objective_parts(rri_ctx* c, double out[3]) {
+    CHECK_CTX(c);
+    if (!c->have_X || !c->have_W || !c->have_T) return fail(c, RRI_ERR_INVALID, "X, W, T must be set");
+    if (c->weighted && !c->have_M) return fail(c, RRI_ERR_INVALID, "weighted handle without a mask");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->rowobj) HIPCHK(c, hipMalloc((void**)&c->rowobj, (size_t)c->n * sizeof(double)));
+    DISPATCH(c, L::resid(c, c->weighted != 0, false, c->rowobj, nullptr));
+    hipLaunchKernelGGL(k_vec_sum_argmax, dim3(1), dim3(1024), 0, c->stream, (const double*)c->rowobj, c->n,
+                       c->dtmp, (i64*)nullptr);
+    double base = 0.0;
+    HIPCHK(c, hipMemcpyAsync(&base, c->dtmp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double nw[3];
+    rri_status r = norms_of(c, c->W, c->n, c->k, c->k, nw);
+    if (r != RRI_OK) return r;
+    out[0] = 0.5 * base;
+    out[1] = nw[1];
+    out[2] = nw[2];
+    return RRI_OK;
+}
+
+rri_status rri_objective(rri_ctx* c, double* out) {
+    CHECK_CTX(c);
+    if (!out) return fail(c, RRI_ERR_INVALID, "out is NULL");
+    double parts[3];
+    rri_status r = rri_objective_parts(c, parts);
+    if (r != RRI_OK) return r;
+    double nt[3];
+    r = norms_of(c, c->T, c->k, c->d, c->LD, nt);
+    if (r != RRI_OK) return r;
+    const rri_params& q = c->prm;
+    // base + wr2 + tr2 + tr1 + wr1 (nmf.py:83-91)
+    *out = parts[0] + 0.5 * q.reg_w_l2 * parts[1] + 0.5 * q.reg_t_l2 * nt[1] + q.reg_t_l1 * nt[2] +
+           q.reg_w_l1 * parts[2];
+    return RRI_OK;
+}
+
+rri_status rri_argmax_rows(rri_ctx* c, int32_t* out_host) {
+    CHECK_CTX(c);
+    if (!out_host) return fail(c, RRI_ERR_INVALID, "out is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    int* dev = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dev, (size_t)c->n * sizeof(int)));
+    DISPATCH(c, L::argmax_rows(c, dev));
+    hipError_t e = hipMemcpyAsync(out_host, dev, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "argmax failed: %s", hipGetErrorString(e));
+    return RRI_OK;
+}
+
+rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, int64_t count, double lo, double hi,
+                           double* out) {
+    CHECK_CTX(c);
+    if (!ij || !vals || !out || count < 1) return fail(c, RRI_ERR_INVALID, "bad entry list");
+    for (i64 e = 0; e < count; ++e)
+        if (ij[2 * e] < 0 || ij[2 * e] >= c->n || ij[2 * e + 1] < 0 || ij[2 * e + 1] >= c->d)
+            return fail(c, RRI_ERR_INVALID, "entry %lld out of range", e);
+    HIPCHK(c, hipSetDevice(c->device));
+    i64* dij = nullptr;
+    double* dv = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dij, (size_t)count * 2 * sizeof(i64)));
+    hipError_t e = hipMalloc((void**)&dv, (size_t)count * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(dij, ij, (size_t)count * 2 * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    double h[256];
+    if (e == hipSuccess) {
+        DISPATCH(c, L::masked_sqerr(c, dij, dv, count, lo, hi));
+        e = hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dij);
+    if (dv) (void)hipFree(dv);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "masked rmse failed: %s", hipGetErrorString(e));
+    double s = 0.0;
+    for (int b = 0; b < 256; ++b) s += h[b];
+    *out = std::sqrt(s / (double)count);
+    return RRI_OK;
+}
+
+rri_status rri_snapshot(rri_ctx* c) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->Wprev) HIPCHK(c, hipMalloc(&c->Wprev, (size_t)c->n * c->k * c->es));
+    if (!c->Tprev) HIPCHK(c, hipMalloc(&c->Tprev, (size_t)c->k * c->LD * c->es));
+    HIPCHK(c, hipMemcpyAsync(c->Wprev, c->W, (size_t)c->n * c->k * c->es, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->Tprev, c->T, (size_t)c->k * c->LD * c->es, hipMemcpyDeviceToDevice, c->stream));
+    return RRI_OK;
+}
+
+rri_status rri_rollback(rri_ctx* c) {
+    CHECK_CTX(c);
+    if (!c->Wprev || !c->Tprev) return fail(c, RRI_ERR_INVALID, "no snapshot taken");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->W, c->Wprev, (size_t)c->n * c->k * c->es, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->T, c->Tprev, (size_t)c->k * c->LD * c->es, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    invalidate(c);
+    c->pending_wcheck = false;
+    return RRI_OK;
+}
+
+// ---- row-sharded multi-GPU ---------------------------------------------------------------------------------
+rri_status rri_reduce_buffer(rri_ctx* c, void** dev_ptr, int64_t* n_elems) {
+    CHECK_CTX(c);
+    if (dev_ptr) *dev_ptr = c->red;
+    if (n_elems) *n_elems = c->red_elems;
+    return RRI_OK;
+}
+
+rri_status rri_bind_reduce_buffer(rri_ctx* c, void* dev_ptr, int64_t n_elems) {
+    CHECK_CTX(c);
+    if (!dev_ptr || n_elems < c->red_elems || ((uintptr_t)dev_ptr) % 16)
+        return fail(c, RRI_ERR_INVALID, "reduce buffer needs >= %lld elements, 16-byte aligned", c->red_elems);
+    if (c->own_red && c->red) (void)hipFree(c->red);
+    c->red = dev_ptr;
+    c->own_red = false;
+    invalidate(c);
+    return RRI_OK;
+}
+
+rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
+    CHECK_CTX(c);
+    rri_status r = ready(c);
+    if (r != RRI_OK) return r;
+    if (c->weighted || c->prm.fix_W || c->prm.fix_T || c->k < 2)
+        return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping covers the unweighted flavour with k >= 2 and both halves free");
+    if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->carry_valid || c->carry_topic != t) {
+        // a local column check would see only this rank's rows: keep it pending for the reduced buffer
+        const bool pend = c->pending_wcheck;
+        const int pt = c->pending_wcheck_topic;
+        c->pending_wcheck = false;
+        enqueue_prologue(c, t, 0);
+        c->pending_wcheck = pend;
+        c->pending_wcheck_topic = pt;
+        if (pend) return fail(c, RRI_ERR_INVALID, "carry lost while a sharded column check was pending");
+    }
+    DISPATCH(c, L::reduce(c));
+    return RRI_OK;
+}
+
+rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (t < 0) {  // only the pending column check, against the (all-reduced) buffer
+        if (c->pending_wcheck) {
+            DISPATCH(c, L::check_prev_only(c, c->pending_wcheck_topic, 0, 0));
+            c->pending_wcheck = false;
+        }
+        return RRI_OK;
+    }
+    if (t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    const int chk = c->pending_wcheck ? 1 : 0;
+    DISPATCH(c, L::trow(c, t, chk, c->pending_wcheck_topic, 0));
+    c->pending_wcheck = false;
+    c->carry_valid = false;
+    enqueue_W_half(c, 0, t);
+    return RRI_OK;
+}
+
+rri_status rri_poll(rri_ctx* c) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    DevState s;
+    rri_status r = read_state(c, &s);
+    if (r != RRI_OK) return r;
+    c->run_total = 0;
+    r = status_from_halt(c, s, nullptr);
+    if (s.halt != 0) (void)clear_halt(c);
+    return r;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------------
+rri_status rri_timing_enable(rri_ctx* c, int32_t on) {
+    CHECK_CTX(c);
+    c->timing = on != 0;
+    return RRI_OK;
+}
+
+rri_status rri_timing_read(rri_ctx* c, int32_t id, int64_t* launches, double* total_ms) {
+    CHECK_CTX(c);
+    if (id < 0 || id > 3) return fail(c, RRI_ERR_INVALID, "kernel_id out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (auto& tl : c->timed[id]) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, tl.a, tl.b));
+        tot += ms;
+        c->event_pool.push_back(tl.a);
+        c->event_pool.push_back(tl.b);
+    }
+    if (launches) *launches = (int64_t)c->timed[id].size();
+    if (total_ms) *total_ms = tot;
+    c->timed[id].clear();
+    return RRI_OK;
+}
+
+rri_status rri_synchronize(rri_ctx* c) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
+rri_status rri_bench_stream_copy(rri_ctx* c, int32_t reps, double* avg_ms) {
+    CHECK_CTX(c);
+    if (!c->have_X || reps < 1) return fail(c, RRI_ERR_INVALID, "X must be set and reps >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->n * c->ldx * c->es;
+    void* dst = nullptr;
+    HIPCHK(c, hipMalloc(&dst, bytes));
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    const i64 nvec = (i64)(bytes / 16);
+    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, c->stream, (const float4*)c->X, (float4*)dst, nvec);
+    (void)hipEventRecord(a, c->stream);
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, c->stream, (const float4*)c->X, (float4*)dst, nvec);
+    (void)hipEventRecord(b, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "stream copy failed: %s", hipGetErrorString(e));
+    if (avg_ms) *avg_ms = ms / reps;
+    return RRI_OK;
+}
+
+rri_status rri_bench_rank1_update(rri_ctx* c, int32_t reps, double* avg_ms) {
+    CHECK_CTX(c);
+    if (!c->have_X || reps < 1) return fail(c, RRI_ERR_INVALID, "X must be set and reps >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    // scratch residual R = copy of X; a = wcol-shaped vector, b = a T row (values are irrelevant to timing,
+    // tiny magnitudes keep R finite over the repetitions)
+    const size_t bytes = (size_t)c->n * c->ldx * c->es;
+    void *R = nullptr, *a = nullptr;
+    HIPCHK(c, hipMalloc(&R, bytes));
+    if (hipMalloc(&a, (size_t)c->n * c->es) != hipSuccess) { (void)hipFree(R); return fail(c, RRI_ERR_HIP, "hipMalloc failed"); }
+    (void)hipMemcpyAsync(R, c->X, bytes, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemsetAsync(a, 0, (size_t)c->n * c->es, c->stream);
+    (void)hipMemsetAsync(c->st, 0, 16, c->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const bool tm = c->timing;
+    c->timing = false;
+    DISPATCH(c, L::rank1(c, R, a, c->T, c->T, a));
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; ++r) DISPATCH(c, L::rank1(c, R, a, c->T, c->T, a));
+    (void)hipEventRecord(e1, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    c->timing = tm;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(R);
+    (void)hipFree(a);
+    invalidate(c);
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "rank-one bench failed: %s", hipGetErrorString(e));
+    if (avg_ms) *avg_ms = ms / reps;
+    return RRI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,770 @@
+// rri_kernels.hpp -- hand-written gfx950 kernels of the RRI topic step (Gram form).
+//
+// One topic step t of nmf.py:415-476 is, in the reference, two BLAS2 products over X:
+//     w_t^T X  (nmf.py:672)   and   X t_t  (nmf.py:729)
+// Here ONE streaming pass over X (k_pass) computes  X t_t  (row dots, for the W-column
+// update of topic t) AND  w_{t+1}^T X  (column sums, for the T-row update of topic t+1):
+// column t+1 of W is not touched between the two (only column t changes in step t), so
+// the fused pass is exact and X is read k (+1) times per sweep instead of 2k.
+//
+// Chain per topic (all on one stream, no host sync):
+//   k_reduce      partial column sums / Gram row  -> reduce buffer (the multi-GPU all-reduce point)
+//   k_trow_numer  numer_T = w^T X - (w^T W)_{-t} T - reg ; closed-form qf_min       (nmf.py:437-447)
+//   k_trow_final  simplex projection / one-hot / reset check; writes T[t,:]          (nmf.py:447,751-761)
+//   k_tgram       T T[t,:]^T (k-vector, entry t zeroed) and ||T[t,:]||^2               (nmf.py:730-734)
+//   k_pass        the X pass (HBM-bound, the roofline kernel)
+//   k_wcol        numer_W = X t - W (T t)_{-t} - reg ; qf_min ; writes W[:,t];
+//                 Gram row / norm partials of the NEXT topic                             (nmf.py:464-469,673-676)
+// Rare branches (reset conditions, unbounded problems, dead columns) set DevState::halt;
+// every later kernel of the queue then returns at once and the host resolves the event.
+#pragma once
+#include <type_traits>
+
+#include "rri_device.hpp"
+
+namespace rri {
+
+enum { HALT_EVENT_RESET_T = 1, HALT_EVENT_RESET_W = 2,
+       HALT_ERR_UNBOUNDED = -4, HALT_ERR_W_COL_ZERO = -5, HALT_ERR_NOT_IMPLEMENTED = -6 };
+enum { RESET_NONE = 0, RESET_MAX_RESID = 1, RESET_RANDOM = 2 };
+
+struct DevState {
+    int halt;        // 0 = running, >0 event, <0 error
+    int halt_topic;  // topic the event refers to
+    int halt_sweep;  // position of the DETECTING step
+    int halt_pos;
+    int tmode;       // qf_min branch of the current T row: 0 c>0, 1 c<=0 bounds, 2 c<=0 one-hot
+    int proj_iters;  // Michelot iterations of the last projection (diagnostic)
+    int pad0, pad1;
+    double nt1;      // 1-norm of the unprojected T-row solution (qf_min's nx, nmf.py:447)
+    double nt;       // ||T[t,:]||^2
+    double sumT;
+    double theta;
+};
+
+struct KParams {
+    int fix_W, fix_T, project_T, has_trs, has_wrs, reset_method, resets_left, pad;
+    double t_row_sum, w_row_sum, reg_w_l1, reg_w_l2, reg_t_l1, reg_t_l2, eps;
+};
+
+// =========================================================================================
+// k_pass: the fused streaming pass over X.
+//   grid = npanels * nrb workgroups of 256 threads (4 waves).  A workgroup owns one column
+//   panel (PW = 64 lanes * 16 B * NCH) of one row block; its waves take rows round-robin.
+//   Per row a wave issues NCH 16-byte loads per lane (coalesced 1 KiB each), keeps U rows in
+//   flight, holds the active T-row slice (DO_Y) and the column-sum accumulators (DO_Z) in
+//   registers, and reads the active W-column entries from LDS.
+// =========================================================================================
+//   UPD: the explicit-residual form north_star names: X is the residual R and the pass first
+//   applies the rank-one update R <- R - a b^T (a from LDS, b slice in registers), writes R back
+//   and takes the row dots / column sums of the UPDATED residual in the same sweep over memory.
+template <typename S, bool DO_Y, bool DO_Z, bool UPD>
+__global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, S, const S>::type* __restrict__ X,
+                                              i64 ldx, int n, int ncols,
+                                              const S* __restrict__ trow, const S* __restrict__ wcol,
+                                              S* __restrict__ Ypart, S* __restrict__ Zpart, i64 ldz,
+                                              int rpb, int npanels, const S* __restrict__ avec,
+                                              const S* __restrict__ bvec, const DevState* __restrict__ st) {
+    typedef typename V16<S>::type V;
+    constexpr int VN = V16<S>::N;
+    constexpr int NCH = 4;
+    constexpr int U = 4;
+    constexpr int PW = 64 * VN * NCH;
+    if (st->halt) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V* zsh = reinterpret_cast<V*>(smem);                                  // [4][NCH*64]
+    S* wsh = reinterpret_cast<S*>(smem + 4 * NCH * 64 * sizeof(V));       // [rpb]
+    S* ash = wsh + rpb;                                                   // [rpb] (UPD)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int panel = blockIdx.x % npanels;
+    const int rb = blockIdx.x / npanels;
+    const int row0 = rb * rpb;
+    const int row1 = min(n, row0 + rpb);
+    const int colb = panel * PW + lane * VN;
+    if (DO_Z || UPD) {
+        for (int i = threadIdx.x; i < row1 - row0; i += 256) {
+            if (DO_Z) wsh[i] = wcol[row0 + i];
+            if (UPD) ash[i] = avec[row0 + i];
+        }
+        __syncthreads();
+    }
+    bool ok[NCH];
+    V tv[NCH], zacc[NCH], bv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = colb + c * 64 * VN;
+        ok[c] = col < ncols;
+        tv[c] = vzero((V*)0);
+        zacc[c] = vzero((V*)0);
+        bv[c] = vzero((V*)0);
+        if (DO_Y && ok[c]) tv[c] = *reinterpret_cast<const V*>(trow + col);
+        if (UPD && ok[c]) bv[c] = *reinterpret_cast<const V*>(bvec + col);
+    }
+    const bool full = (panel + 1) * PW <= ncols;  // wave-uniform: no column predication needed
+
+    for (int r = row0 + wave; r < row1; r += 4 * U) {
+        V x[U][NCH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + 4 * u;
+            if (rr < row1) {
+                const S* xp = X + (i64)rr * ldx + colb;
+                if (full) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) x[u][c] = *reinterpret_cast<const V*>(xp + c * 64 * VN);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        x[u][c] = ok[c] ? *reinterpret_cast<const V*>(xp + c * 64 * VN) : vzero((V*)0);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) x[u][c] = vzero((V*)0);
+            }
+        }
+        S ys[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + 4 * u;
+            S wv = S(0);
+            if (DO_Z && rr < row1) wv = wsh[rr - row0];
+            if constexpr (UPD) if (rr < row1) {
+                const S na = -ash[rr - row0];
+                S* xo = X + (i64)rr * ldx + colb;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    vaxpy(x[u][c], na, bv[c]);
+                    if (full || ok[c]) *reinterpret_cast<V*>(xo + c * 64 * VN) = x[u][c];
+                }
+            }
+            S yp = S(0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (DO_Y) yp = vdot(x[u][c], tv[c], yp);
+                if (DO_Z) vaxpy(zacc[c], wv, x[u][c]);
+            }
+            if (DO_Y) ys[u] = wave_sum<S>(yp);
+        }
+        if (DO_Y) {
+            S yv = ys[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u)
+                if (lane == u) yv = ys[u];
+            const int rr = r + 4 * lane;
+            if (lane < U && rr < row1) Ypart[(i64)panel * n + rr] = yv;
+        }
+    }
+    if (DO_Z) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) zsh[(wave * NCH + c) * 64 + lane] = zacc[c];
+        __syncthreads();
+        const int tid = threadIdx.x;
+        V s = zsh[tid];
+        vadd(s, zsh[256 + tid]);
+        vadd(s, zsh[512 + tid]);
+        vadd(s, zsh[768 + tid]);
+        const int col = panel * PW + (tid >> 6) * 64 * VN + (tid & 63) * VN;
+        if (col < ldz) *reinterpret_cast<V*>(Zpart + (i64)rb * ldz + col) = s;
+    }
+}
+
+// =========================================================================================
+// k_wcol: W-column update of topic t (UPDATE) and Gram-row / norm partials + contiguous copy
+// of the column tx the next pass streams against (CARRY).  blockDim = RW rows (64/128/256); the RW x k tile of
+// W is staged in LDS (coalesced global reads, conflict-free row reads with stride k+1).
+// Gpart[b][0..k) = sum_i wn_i W[i,:], [k] = sum wn_i^2, [k+1] = sum_i W[i,t] (new).
+// =========================================================================================
+template <typename S, bool UPDATE, bool CARRY>
+__global__ __launch_bounds__(256) void k_wcol(S* __restrict__ W, int n, int k, int t, int tn, int tx, const S* __restrict__ Ypart,
+                       int npanels, const S* __restrict__ Tt, S* __restrict__ wcol,
+                       double* __restrict__ Gpart, int sweep, KParams p, DevState* st) {
+    if (st->halt) return;
+    const int RW = blockDim.x;
+    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* scratch = reinterpret_cast<double*>(smem);                 // 40 doubles
+    double* gsh = scratch + 40;                                        // [4][k]
+    S* tts = reinterpret_cast<S*>(gsh + 4 * k);                        // [k]
+    S* wnsh = tts + k;                                                 // [RW]
+    S* wt = wnsh + RW;                                                 // [RW][k+1]
+    const int kp = k + 1;
+    const i64 row0 = (i64)blockIdx.x * RW;
+    const int rows_here = (int)min((i64)RW, (i64)n - row0);
+
+    double cden = 0.0;
+    int mode = 0;
+    if (UPDATE) {
+        cden = st->nt + p.reg_w_l2;  // denom = nt + reg_w_l2 (nmf.py:465)
+        if (!(cden > 0.0)) {
+            // scalar c<=0 with s=None (optimization.py:60-67): entries jump to ub, or unbounded
+            if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;
+            else {
+                if (blockIdx.x == 0 && tid == 0) {
+                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+                }
+                return;
+            }
+        }
+        for (int l = tid; l < k; l += RW) tts[l] = Tt[l];
+    }
+    for (int idx = tid; idx < RW * k; idx += RW) {
+        const int r = idx / k, l = idx - r * k;
+        wt[r * kp + l] = (idx < rows_here * k) ? W[row0 * k + idx] : S(0);
+    }
+    __syncthreads();
+    const bool valid = tid < rows_here;
+    const i64 i = row0 + tid;
+    S wnew = S(0);
+    if (UPDATE && valid) {
+        S y = S(0);
+        for (int q = 0; q < npanels; ++q) y += Ypart[(i64)q * n + i];
+        S dotv = S(0);
+        for (int l = 0; l < k; ++l) dotv = fma(wt[tid * kp + l], tts[l], dotv);
+        const S numer = (y - dotv) - (S)p.reg_w_l1;
+        if (mode == 0) wnew = fmax(numer, S(0)) / ((S)cden + (S)p.eps);
+        else wnew = ((double)(-numer) + cden < 0.0) ? (S)p.w_row_sum : S(0);
+        wt[tid * kp + t] = wnew;
+        W[i * k + t] = wnew;
+    }
+    S wnv = S(0);
+    if (CARRY) {
+        // Gram row of the NEXT topic tn; the pass after next needs column tx contiguous
+        if (valid) { wnv = wt[tid * kp + tn]; wcol[i] = wt[tid * kp + tx]; }
+        wnsh[tid] = wnv;
+    }
+    __syncthreads();
+    if (CARRY) {
+        const int g = tid >> 6, l0 = tid & 63;
+        for (int l = l0; l < k; l += 64) {
+            double acc = 0.0;
+            for (int r = g * 64; r < g * 64 + 64; ++r) acc += (double)wnsh[r] * (double)wt[r * kp + l];
+            gsh[g * k + l] = acc;
+        }
+    }
+    const double nwp = block_sum(CARRY ? (double)wnv * (double)wnv : 0.0, scratch);
+    const double swp = block_sum(UPDATE ? (double)wnew : 0.0, scratch);  // also orders gsh writes
+    double* gp = Gpart + (i64)blockIdx.x * (k + 2);
+    const int ng = RW >> 6;
+    for (int l = tid; l < k; l += RW) {
+        double a = 0.0;
+        if (CARRY) for (int g = 0; g < ng; ++g) a += gsh[g * k + l];
+        gp[l] = a;
+    }
+    if (tid == 0) { gp[k] = nwp; gp[k + 1] = swp; }
+}
+
+// =========================================================================================
+// k_reduce: fixed-order reduction of the row-block partials into the reduce buffer
+//   red[0..ldz) = w^T X ; red[ldz..ldz+k) = w^T W ; red[ldz+k] = ||w||^2 ; red[ldz+k+1] = sum W[:,tprev]
+// (in the row-sharded multi-GPU run this buffer is what the ranks all-reduce).
+// =========================================================================================
+template <typename S>
+__global__ __launch_bounds__(256) void k_reduce(const S* __restrict__ Zpart, i64 ldz, int nrb,
+                                                const double* __restrict__ Gpart, int nwb, int k,
+                                                S* __restrict__ red, const DevState* __restrict__ st) {
+    if (st->halt) return;
+    const int tid = threadIdx.x;
+    if (blockIdx.x + 1 < gridDim.x) {
+        const i64 j = (i64)blockIdx.x * 256 + tid;
+        if (j < ldz) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int b = 0;
+            for (; b + 4 <= nrb; b += 4) {
+                a0 += (double)Zpart[(i64)(b + 0) * ldz + j];
+                a1 += (double)Zpart[(i64)(b + 1) * ldz + j];
+                a2 += (double)Zpart[(i64)(b + 2) * ldz + j];
+                a3 += (double)Zpart[(i64)(b + 3) * ldz + j];
+            }
+            for (; b < nrb; ++b) a0 += (double)Zpart[(i64)b * ldz + j];
+            red[j] = (S)((a0 + a1) + (a2 + a3));
+        }
+    } else {
+        for (int l = tid; l < k + 2; l += 256) {
+            double a = 0.0;
+            for (int b = 0; b < nwb; ++b) a += Gpart[(i64)b * (k + 2) + l];
+            red[ldz + l] = (S)a;
+        }
+    }
+}
+
+// =========================================================================================
+// k_trow_numer: numerator of the T-row update and the closed-form minimiser (before any
+// simplex projection).  Also evaluates the pending W-column check of the previous topic
+// (_check_reset_W + assert, nmf.py:471-476) from the reduced column sum.
+// =========================================================================================
+template <typename S>
+__global__ __launch_bounds__(256) void k_trow_numer(const S* __restrict__ T, i64 ldt, int d, int k, int t,
+                                                    const S* __restrict__ red, i64 ldz, S* __restrict__ xraw,
+                                                    double* __restrict__ tpart, i64* __restrict__ tpart_idx,
+                                                    int check_prev, int tprev, int sweep, KParams p,
+                                                    DevState* st) {
+    if (st->halt) return;
+    const int tid = threadIdx.x;
+    __shared__ double scratch[40];
+    __shared__ S gsh[512];
+    const double nw = (double)red[ldz + k];
+    if (check_prev) {
+        const double sw = (double)red[ldz + k + 1];
+        const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(sw > 0.0);
+        if (ev || err) {
+            if (blockIdx.x == 0 && tid == 0) {
+                st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+                st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = t;
+            }
+            return;
+        }
+    }
+    const double c = nw + p.reg_t_l2;  // denom = nw + reg_t_l2 (nmf.py:438)
+    const bool project = p.project_T && p.has_trs;
+    int mode = 0;
+    if (!(c > 0.0)) {
+        if (!project) {
+            if (p.has_trs && p.t_row_sum != 0.0) mode = 1;
+            else mode = HALT_ERR_UNBOUNDED;
+        } else {
+            mode = (p.t_row_sum == 1.0) ? 2 : HALT_ERR_NOT_IMPLEMENTED;
+        }
+        if (mode < 0) {
+            if (blockIdx.x == 0 && tid == 0) {
+                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+            }
+            return;
+        }
+    }
+    for (int l = tid; l < k; l += 256) gsh[l] = (l == t) ? S(0) : red[ldz + l];
+    __syncthreads();
+    const i64 j = (i64)blockIdx.x * 256 + tid;
+    S x = S(0);
+    double mx = -1.0e300;
+    if (j < d) {
+        S acc = S(0);
+        for (int l = 0; l < k; ++l) acc = fma(gsh[l], T[(i64)l * ldt + j], acc);
+        const S numer = (red[j] - acc) - (S)p.reg_t_l1;
+        if (mode == 0) x = fmax(numer, S(0)) / ((S)c + (S)p.eps);
+        else if (mode == 1) x = ((double)(-numer) + c < 0.0) ? (S)p.t_row_sum : S(0);
+        else { x = numer; mx = (double)numer; }
+        xraw[j] = x;
+    }
+    if (mode != 2) {
+        const double s = block_sum((double)x, scratch);
+        if (tid == 0) tpart[blockIdx.x] = s;
+    } else {
+        i64 idx = (j < d) ? j : (i64)0x7fffffffffffffffLL;
+        wave_argmax(mx, idx);
+        __shared__ double wm[4];
+        __shared__ i64 wi[4];
+        if ((tid & 63) == 0) { wm[tid >> 6] = mx; wi[tid >> 6] = idx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (wm[w] > wm[0] || (wm[w] == wm[0] && wi[w] < wi[0])) { wm[0] = wm[w]; wi[0] = wi[w]; }
+            tpart[blockIdx.x] = wm[0];
+            tpart_idx[blockIdx.x] = wi[0];
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) st->tmode = mode;
+}
+
+// Michelot's fixed point for the Euclidean simplex projection (same active set, hence the same
+// theta = (sum_active - s)/|active|, as the sort of matrixops.py:58-63).  Single workgroup.
+template <typename S>
+__device__ double simplex_theta(const S* v, int d, double s, double* scratch, int* iters) {
+    double theta = -1.0e300;
+    i64 cnt_prev = -1;
+    int it = 0;
+    for (; it < d + 2; ++it) {
+        double sum = 0.0, cnt = 0.0;
+        for (int j = threadIdx.x; j < d; j += blockDim.x) {
+            const double x = (double)v[j];
+            if (x > theta) { sum += x; cnt += 1.0; }
+        }
+        sum = block_sum(sum, scratch);
+        cnt = block_sum(cnt, scratch);
+        const i64 ci = (i64)cnt;
+        if (ci == cnt_prev || ci == 0) break;
+        theta = (sum - s) / cnt;
+        cnt_prev = ci;
+    }
+    *iters = it;
+    return theta;
+}
+
+// =========================================================================================
+// k_trow_final: finishes qf_min (simplex projection or one-hot), the row checks of
+// _project_and_check_reset_t (nmf.py:751-769) and writes T[t,:].  One workgroup of 1024.
+// =========================================================================================
+template <typename S>
+__global__ __launch_bounds__(1024) void k_trow_final(S* __restrict__ T, i64 ldt, int d, int t,
+                                                     S* __restrict__ xraw, const double* __restrict__ tpart,
+                                                     const i64* __restrict__ tpart_idx, int nblk, int sweep,
+                                                     KParams p, DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const int tid = threadIdx.x;
+    const int mode = st->tmode;
+    const bool project = p.project_T && p.has_trs;
+    double nx = 1.0;
+    int iters = 0;
+    if (mode == 2) {
+        double bm = tpart[0];
+        i64 bi = tpart_idx[0];
+        for (int b = 1; b < nblk; ++b)
+            if (tpart[b] > bm) { bm = tpart[b]; bi = tpart_idx[b]; }
+        for (int j = tid; j < d; j += blockDim.x) xraw[j] = (j == bi) ? S(1) : S(0);
+    } else if (mode == 0) {
+        nx = 0.0;
+        for (int b = 0; b < nblk; ++b) nx += tpart[b];
+        if (project) {
+            const double th = simplex_theta<S>(xraw, d, p.t_row_sum, scratch, &iters);
+            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - (S)th, S(0));
+            if (tid == 0) st->theta = th;
+        }
+    }
+    __syncthreads();
+    double sumT = 0.0;
+    for (int j = tid; j < d; j += blockDim.x) sumT += (double)xraw[j];
+    sumT = block_sum(sumT, scratch);
+    bool event = false;
+    if (sumT > 1e-10 || p.reset_method == RESET_NONE) {
+        // nmf.py:759-761: project again when the row is not on the simplex to 1e-15
+        if (p.has_trs && p.t_row_sum != 0.0 && p.project_T && fabs(sumT - p.t_row_sum) > 1e-15) {
+            int it2 = 0;
+            const double th = simplex_theta<S>(xraw, d, p.t_row_sum, scratch, &it2);
+            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - (S)th, S(0));
+            iters += it2;
+        }
+    } else if (p.resets_left > 0) {
+        event = true;
+    }
+    __syncthreads();
+    for (int j = tid; j < d; j += blockDim.x) T[(i64)t * ldt + j] = xraw[j];
+    if (tid == 0) {
+        st->nt1 = nx;
+        st->sumT = sumT;
+        st->proj_iters = iters;
+        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
+    }
+}
+
+// k_tgram: Tt[l] = <T[l,:], T[t,:]> (entry t zeroed, nmf.py:730-732); nt = ||T[t,:]||^2 (:734).
+template <typename S>
+__global__ __launch_bounds__(256) void k_tgram(const S* __restrict__ T, i64 ldt, int d, int t,
+                                               S* __restrict__ Tt, DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const int l = blockIdx.x;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256)
+        acc += (double)T[(i64)l * ldt + j] * (double)T[(i64)t * ldt + j];
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        if (l == t) { st->nt = acc; Tt[l] = S(0); }
+        else Tt[l] = (S)acc;
+    }
+}
+
+// W[:,t] *= nt1 (nmf.py:450-452); only observable when fix_W keeps the column.
+template <typename S>
+__global__ __launch_bounds__(256) void k_scale_wcol(S* W, int n, int k, int t, const DevState* st) {
+    if (st->halt) return;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) W[i * k + t] = W[i * k + t] * (S)st->nt1;
+}
+
+// wcol[i] = W[i, col]: contiguous copy of the active column for the streaming pass
+template <typename S>
+__global__ __launch_bounds__(256) void k_extract_col(const S* __restrict__ W, int n, int k, int col,
+                                                     S* __restrict__ wcol, const DevState* __restrict__ st) {
+    if (st->halt) return;
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) wcol[i] = W[i * k + col];
+}
+
+// the W-column check alone, against the reduced buffer (row-sharded runs, after the last sweep)
+template <typename S>
+__global__ __launch_bounds__(64) void k_check_red(const S* __restrict__ red, i64 ldz, int k, int tprev, int sweep, int pos, KParams p,
+                            DevState* st) {
+    if (st->halt) return;
+    if (threadIdx.x == 0) {
+        const double sw = (double)red[ldz + k + 1];
+        const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(sw > 0.0);
+        if (ev || err) {
+            st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+        }
+    }
+}
+
+// stand-alone W-column check for the paths without a following T-row step
+template <typename S>
+__global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ Gpart, int nwb, int k, int tprev, int sweep, int pos,
+                             KParams p, DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nwb; b += blockDim.x) a += Gpart[(i64)b * (k + 2) + k + 1];
+    a = block_sum(a, scratch);
+    if (threadIdx.x == 0) {
+        const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(a > 0.0);
+        if (ev || err) {
+            st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+        }
+    }
+}
+
+// =========================================================================================
+// k_proj_rows: Euclidean projection of every row of W on the simplex of radius s (scalar) or
+// s_vec[i] (matrixops.py:72-100; nmf.py:481-484, 519-529).  One thread per row, tile in LDS.
+// =========================================================================================
+template <typename S>
+__global__ __launch_bounds__(256) void k_proj_rows(S* __restrict__ W, int n, int k, double s_scalar, const double* __restrict__ s_vec) {
+    const int RW = blockDim.x, tid = threadIdx.x, kp = k + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    S* wt = reinterpret_cast<S*>(smem);
+    const i64 row0 = (i64)blockIdx.x * RW;
+    const int rows_here = (int)min((i64)RW, (i64)n - row0);
+    for (int idx = tid; idx < rows_here * k; idx += RW) {
+        const int r = idx / k, l = idx - r * k;
+        wt[r * kp + l] = W[row0 * k + idx];
+    }
+    __syncthreads();
+    if (tid < rows_here) {
+        const double s = s_vec ? s_vec[row0 + tid] : s_scalar;
+        S* v = wt + tid * kp;
+        double theta = -1.0e300;
+        int cnt_prev = -1;
+        for (int it = 0; it < k + 2; ++it) {
+            double sum = 0.0;
+            int cnt = 0;
+            for (int l = 0; l < k; ++l) {
+                const double x = (double)v[l];
+                if (x > theta) { sum += x; ++cnt; }
+            }
+            if (cnt == cnt_prev || cnt == 0) break;
+            theta = (sum - s) / (double)cnt;
+            cnt_prev = cnt;
+        }
+        for (int l = 0; l < k; ++l) v[l] = fmax(v[l] - (S)theta, S(0));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows_here * k; idx += RW) {
+        const int r = idx / k, l = idx - r * k;
+        W[row0 * k + idx] = wt[r * kp + l];
+    }
+}
+
+// =========================================================================================
+// k_resid: E = X - W T on 64x64 tiles with a 4x4 register tile per thread (a dense k-panel
+// GEMM on the vector ALU; not on the per-sweep hot path).  Used for
+//   - true_objective (nmf.py:77-83): rowobj[i] = sum_j (Wm_ij) E_ij^2
+//   - 'max_resid_document' (nmf.py:771-773): rowpos[i] = sum_j max(E_ij,0)^2
+//   - WRITE_E: the masked residual M .* E of the weighted flavour.
+// grid = ceil(n/64) workgroups of 256; each walks all column tiles (deterministic sums).
+// =========================================================================================
+template <typename S, bool MASKED, bool WRITE_E>
+__global__ __launch_bounds__(256) void k_resid(const S* __restrict__ X, i64 ldx, const S* __restrict__ M, i64 ldm,
+                                               const S* __restrict__ W, const S* __restrict__ T, i64 ldt,
+                                               int n, int d, int k, double* __restrict__ rowobj,
+                                               double* __restrict__ rowpos, S* __restrict__ E, i64 lde) {
+    constexpr int KC = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    S* Wsh = reinterpret_cast<S*>(smem);          // [k][64]  (transposed tile of W)
+    S* Tsh = Wsh + (size_t)k * 64;                 // [KC][64]
+    double* red = reinterpret_cast<double*>(Tsh + KC * 64);  // [64][17]
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const i64 row0 = (i64)blockIdx.x * 64;
+    for (int idx = tid; idx < 64 * k; idx += 256) {
+        const int r = idx / k, l = idx - r * k;
+        Wsh[l * 64 + r] = (row0 + r < n) ? W[(row0 + r) * k + l] : S(0);
+    }
+    double so[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
+    for (i64 c0 = 0; c0 < d; c0 += 64) {
+        S acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = S(0);
+        for (int l0 = 0; l0 < k; l0 += KC) {
+            const int kc = min(KC, k - l0);
+            __syncthreads();
+            for (int idx = tid; idx < kc * 64; idx += 256) {
+                const int l = idx >> 6, c = idx & 63;
+                Tsh[l * 64 + c] = (c0 + c < d) ? T[(i64)(l0 + l) * ldt + c0 + c] : S(0);
+            }
+            __syncthreads();
+            for (int l = 0; l < kc; ++l) {
+                S wv[4], tv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) wv[a] = Wsh[(l0 + l) * 64 + ty * 4 + a];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) tv[b] = Tsh[l * 64 + tx * 4 + b];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(wv[a], tv[b], acc[a][b]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const i64 i = row0 + ty * 4 + a;
+            if (i >= n) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const i64 j = c0 + tx * 4 + b;
+                if (j >= d) continue;
+                S e = X[i * ldx + j] - acc[a][b];
+                const S m = MASKED ? M[i * ldm + j] : S(1);
+                if (WRITE_E) E[i * lde + j] = m * e;
+                so[a] += (double)m * (double)e * (double)e;
+                const double ep = e > S(0) ? (double)e : 0.0;
+                sp[a] += ep * ep;
+            }
+        }
+    }
+    __syncthreads();
+    // reduce the 16 column-group partials of every row in a fixed order
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) red[(ty * 4 + a) * 17 + tx] = pass == 0 ? so[a] : sp[a];
+        __syncthreads();
+        if (tid < 64 && row0 + tid < n) {
+            double s = 0.0;
+            for (int q = 0; q < 16; ++q) s += red[tid * 17 + q];
+            if (pass == 0) { if (rowobj) rowobj[row0 + tid] = s; }
+            else { if (rowpos) rowpos[row0 + tid] = s; }
+        }
+        __syncthreads();
+    }
+}
+
+// partial sums of v, v^2 and |v| over a strided matrix: out[b] = {sum, sumsq, sumabs}
+template <typename S>
+__global__ __launch_bounds__(256) void k_norms(const S* __restrict__ A, i64 rows, i64 cols, i64 ld,
+                                               double* __restrict__ out) {
+    __shared__ double scratch[40];
+    double s1 = 0, s2 = 0, s3 = 0;
+    const i64 total = rows * cols;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 r = idx / cols, c = idx - r * cols;
+        const double v = (double)A[r * ld + c];
+        s1 += v; s2 += v * v; s3 += fabs(v);
+    }
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch);
+    s3 = block_sum(s3, scratch);
+    if (threadIdx.x == 0) { out[blockIdx.x * 3 + 0] = s1; out[blockIdx.x * 3 + 1] = s2; out[blockIdx.x * 3 + 2] = s3; }
+}
+
+// sum of a double vector -> out[0]; argmax (first index) -> out_idx[0].  One workgroup.
+__global__ __launch_bounds__(1024) void k_vec_sum_argmax(const double* __restrict__ v, i64 n, double* out_sum,
+                                                         i64* out_idx) {
+    __shared__ double scratch[40];
+    __shared__ double wm[16];
+    __shared__ i64 wi[16];
+    double s = 0.0, mx = -1.0e300;
+    i64 mi = (i64)0x7fffffffffffffffLL;
+    for (i64 i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = v[i];
+        s += x;
+        if (x > mx) { mx = x; mi = i; }   // ascending i per thread: keeps the first index
+    }
+    s = block_sum(s, scratch);
+    wave_argmax(mx, mi);
+    if ((threadIdx.x & 63) == 0) { wm[threadIdx.x >> 6] = mx; wi[threadIdx.x >> 6] = mi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (wm[w] > wm[0] || (wm[w] == wm[0] && wi[w] < wi[0])) { wm[0] = wm[w]; wi[0] = wi[w]; }
+        if (out_sum) out_sum[0] = s;
+        if (out_idx) out_idx[0] = wi[0];
+    }
+}
+
+// 'max_resid_document' reset, step 1: row = max(X[mi,:] - W[mi,:] T, 0) (nmf.py:771,774)
+template <typename S>
+__global__ __launch_bounds__(256) void k_reset_row(const S* __restrict__ X, i64 ldx, const S* __restrict__ W,
+                                                   const S* __restrict__ T, i64 ldt, int d, int k,
+                                                   const i64* __restrict__ mi_ptr, S* __restrict__ rowout) {
+    const i64 mi = *mi_ptr;
+    const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    S acc = S(0);
+    for (int l = 0; l < k; ++l) acc = fma(W[mi * k + l], T[(i64)l * ldt + j], acc);
+    rowout[j] = fmax(X[mi * ldx + j] - acc, S(0));
+}
+// step 2: T[t,:] = row ; W[:,t] = e_mi (nmf.py:774-776)
+template <typename S>
+__global__ __launch_bounds__(256) void k_reset_commit(S* __restrict__ W, S* __restrict__ T, i64 ldt, int n, int d,
+                                                      int k, int t, const i64* __restrict__ mi_ptr,
+                                                      const S* __restrict__ rowin) {
+    const i64 mi = *mi_ptr;
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (idx < d) T[(i64)t * ldt + idx] = rowin[idx];
+    if (idx < n) W[idx * k + t] = (idx == mi) ? S(1) : S(0);
+}
+// explicit reset vectors ('random', nmf.py:778-783): T[t,:] and W[:,t] from double buffers
+template <typename S>
+__global__ __launch_bounds__(256) void k_set_row_col(S* __restrict__ W, S* __restrict__ T, i64 ldt, int n, int d,
+                                                     int k, int t, const double* __restrict__ trow,
+                                                     const double* __restrict__ wcolv) {
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (trow && idx < d) T[(i64)t * ldt + idx] = (S)trow[idx];
+    if (wcolv && idx < n) W[idx * k + t] = (S)wcolv[idx];
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_argmax_rows(const S* __restrict__ W, int n, int k, int* __restrict__ out) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    S best = W[i * k];
+    int bi = 0;
+    for (int l = 1; l < k; ++l) {
+        const S v = W[i * k + l];
+        if (v > best) { best = v; bi = l; }
+    }
+    out[i] = bi;
+}
+
+// sum over listed entries of (clip((W T)_ij) - val)^2  (sklearn_interface.py:85-91,172-182)
+template <typename S>
+__global__ __launch_bounds__(256) void k_masked_sqerr(const S* __restrict__ W, const S* __restrict__ T, i64 ldt,
+                                                      int k, const i64* __restrict__ ij,
+                                                      const double* __restrict__ vals, i64 count, double lo,
+                                                      double hi, double* __restrict__ out) {
+    __shared__ double scratch[40];
+    double s = 0.0;
+    for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < count; e += (i64)gridDim.x * 256) {
+        const i64 i = ij[2 * e], j = ij[2 * e + 1];
+        S acc = S(0);
+        for (int l = 0; l < k; ++l) acc = fma(W[i * k + l], T[(i64)l * ldt + j], acc);
+        double pr = (double)acc;
+        pr = pr < lo ? lo : (pr > hi ? hi : pr);
+        const double df = pr - vals[e];
+        s += df * df;
+    }
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// 2-D copy with type conversion (host staging -> padded device layout)
+template <typename Src, typename Dst>
+__global__ __launch_bounds__(256) void k_convert2d(const Src* __restrict__ src, i64 lds_, Dst* __restrict__ dst,
+                                                   i64 ldd, i64 rows, i64 cols) {
+    const i64 total = rows * cols;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 r = idx / cols, c = idx - r * cols;
+        dst[r * ldd + c] = (Dst)src[r * lds_ + c];
+    }
+}
+
+// plain 16-byte streaming copy: the achievable-HBM yardstick measured beside the pass kernel
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, i64 nvec) {
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (i64)gridDim.x * 256) dst[i] = src[i];
+}
+
+}  // namespace rri

@@ -1,0 +1,282 @@
+"""RRIEngine: one device handle (= one nmf() call, or one row shard of it) behind a
+small Python object.  All arithmetic happens in librri_hip.so; this class only moves
+arguments, resolves the rare reset events and maps status codes to the exceptions
+the reference raises (error conventions).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import Params, Event
+
+EPS_DIV = float(np.spacing(10))  # nmf.py:52
+
+_NP2RRI = {np.dtype(np.float32): _capi.RRI_F32, np.dtype(np.float64): _capi.RRI_F64}
+_RESET_CODES = {None: _capi.RESET_NONE, 'max_resid_document': _capi.RESET_MAX_RESID_DOCUMENT,
+                'random': _capi.RESET_RANDOM}
+
+
+def _as_host(a, what):
+    """C-contiguous float32/float64 view or copy of a matrix (never mutates the caller's)."""
+    a = np.asarray(a)
+    if a.dtype not in _NP2RRI:
+        a = a.astype(np.float64)
+    if a.ndim != 2:
+        raise ValueError('%s must be a 2-d array' % what)
+    return np.ascontiguousarray(a)
+
+
+class RRIEngine(object):
+    def __init__(self, n, d, k, dtype=np.float32, weighted=False, device=0, stream=None):
+        self._lib = _capi.load_library()
+        self.n, self.d, self.k = int(n), int(d), int(k)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in _NP2RRI:
+            raise ValueError('dtype must be float32 or float64')
+        self.weighted = bool(weighted)
+        self._h = C.c_void_p()
+        self.n_resets_used = 0
+        self.reset_log = []
+        self.fix_reset_seed = False
+        self._reset_method = None
+        st = self._lib.rri_create(C.byref(self._h), self.n, self.d, self.k, _NP2RRI[self.dtype],
+                                  int(self.weighted), int(device), C.c_void_p(stream or 0))
+        if st != _capi.RRI_OK:
+            msg = self._lib.rri_last_error(None)
+            self._h = C.c_void_p()
+            raise _capi.RRIHipUnavailable('rri_create failed (%d): %s'
+                                          % (st, msg.decode() if msg else '?'))
+
+    # ---- plumbing -----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.rri_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _err(self):
+        m = self._lib.rri_last_error(self._h)
+        return m.decode() if m else ''
+
+    def _check(self, st):
+        if st >= 0:
+            return st
+        msg = self._err()
+        if st == _capi.RRI_ERR_UNBOUNDED:
+            raise ValueError('Minimum objective is unbounded. ' + msg)  # optimization.py:105-107
+        if st == _capi.RRI_ERR_W_COL_ZERO:
+            raise AssertionError('W[:, t] sums to 0')                    # nmf.py:476
+        if st == _capi.RRI_ERR_NOT_IMPLEMENTED:
+            raise NotImplementedError(msg)                               # optimization.py:72-73
+        if st == _capi.RRI_ERR_INVALID:
+            raise ValueError(msg)
+        if st == _capi.RRI_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise RuntimeError('librri_hip: status %d: %s' % (st, msg))
+
+    # ---- data ---------------------------------------------------------------------------
+    def upload_X(self, X):
+        X = _as_host(X, 'X')
+        if X.shape != (self.n, self.d):
+            raise ValueError('X has wrong dimensions')
+        self._check(self._lib.rri_upload_X(self._h, X.ctypes.data, X.strides[0] // X.itemsize, _NP2RRI[X.dtype]))
+
+    def upload_mask(self, M):
+        M = _as_host(M, 'W_mat')
+        if M.shape != (self.n, self.d):
+            raise ValueError('W_mat has wrong dimensions')
+        self._check(self._lib.rri_upload_mask(self._h, M.ctypes.data, M.strides[0] // M.itemsize, _NP2RRI[M.dtype]))
+
+    def bind_X_device(self, ptr, ld):
+        self._check(self._lib.rri_bind_X_device(self._h, C.c_void_p(ptr), int(ld)))
+
+    def bind_mask_device(self, ptr, ld):
+        self._check(self._lib.rri_bind_mask_device(self._h, C.c_void_p(ptr), int(ld)))
+
+    def set_W(self, W):
+        W = _as_host(W, 'W')
+        if W.shape != (self.n, self.k):
+            raise ValueError('W_in has wrong dimensions, must be n*k')   # nmf.py:853-854
+        self._check(self._lib.rri_set_W(self._h, W.ctypes.data, W.strides[0] // W.itemsize, _NP2RRI[W.dtype]))
+
+    def set_T(self, T):
+        T = _as_host(T, 'T')
+        if T.shape != (self.k, self.d):
+            raise ValueError('T_in has wrong dimensions, must be k*d')   # nmf.py:858-859
+        self._check(self._lib.rri_set_T(self._h, T.ctypes.data, T.strides[0] // T.itemsize, _NP2RRI[T.dtype]))
+
+    def get_W(self, dtype=np.float64):
+        out = np.empty((self.n, self.k), dtype=dtype)
+        self._check(self._lib.rri_get_W(self._h, out.ctypes.data, self.k, _NP2RRI[out.dtype]))
+        return out
+
+    def get_T(self, dtype=np.float64):
+        out = np.empty((self.k, self.d), dtype=dtype)
+        self._check(self._lib.rri_get_T(self._h, out.ctypes.data, self.d, _NP2RRI[out.dtype]))
+        return out
+
+    def set_params(self, fix_W=False, fix_T=False, project_T_each_iter=False, t_row_sum=None,
+                   w_row_sum=None, reset_topic_method='max_resid_document', n_resets=23,
+                   reg_w_l1=0.0, reg_w_l2=0.0, reg_t_l1=0.0, reg_t_l2=0.0, fix_reset_seed=False):
+        if reset_topic_method not in _RESET_CODES:
+            raise ValueError('unknown reset_topic_method %r' % (reset_topic_method,))
+        p = Params()
+        p.fix_W, p.fix_T = int(bool(fix_W)), int(bool(fix_T))
+        p.project_T_each_iter = int(bool(project_T_each_iter))
+        p.has_t_row_sum = int(t_row_sum is not None)
+        p.t_row_sum = float(t_row_sum) if t_row_sum is not None else 0.0
+        scalar_w = w_row_sum is not None and np.isscalar(w_row_sum)
+        p.has_w_row_sum = int(scalar_w)
+        p.w_row_sum = float(w_row_sum) if scalar_w else 0.0
+        p.reset_method = _RESET_CODES[reset_topic_method]
+        p.resets_left = int(n_resets)
+        p.reg_w_l1, p.reg_w_l2 = float(reg_w_l1), float(reg_w_l2)
+        p.reg_t_l1, p.reg_t_l2 = float(reg_t_l1), float(reg_t_l2)
+        p.eps_div = EPS_DIV
+        self._params = p
+        self._reset_method = reset_topic_method
+        self.fix_reset_seed = bool(fix_reset_seed)
+        self._check(self._lib.rri_set_params(self._h, C.byref(p)))
+
+    # ---- the hot path -------------------------------------------------------------------
+    def _resolve_event(self):
+        ev = Event()
+        self._check(self._lib.rri_pending_event(self._h, C.byref(ev)))
+        t = ev.topic
+        if self._reset_method == 'max_resid_document':       # nmf.py:770-776 / :804-810
+            row = C.c_int64(-1)
+            self._check(self._lib.rri_apply_reset_max_resid(self._h, t, C.byref(row)))
+            self.reset_log.append((ev.kind, t, int(row.value)))
+        elif self._reset_method == 'random':                 # nmf.py:778-783 / :811-816
+            if self.fix_reset_seed:
+                Trow_now = self.get_T()[t, :]
+                np.random.seed(t + int(np.argmax(Trow_now)))
+            Trow = np.random.rand(1, self.d)
+            Trow = np.ascontiguousarray((Trow / Trow.sum()).ravel())
+            Wcol = np.ascontiguousarray(np.random.rand(self.n))
+            self._check(self._lib.rri_apply_reset_vectors(
+                self._h, t, Trow.ctypes.data_as(C.POINTER(C.c_double)),
+                Wcol.ctypes.data_as(C.POINTER(C.c_double))))
+            self.reset_log.append((ev.kind, t, -1))
+        else:
+            self._check(self._lib.rri_skip_reset(self._h))
+        self.n_resets_used += 1
+
+    def _drive(self, st, done):
+        while st == _capi.RRI_PAUSED:
+            self._resolve_event()
+            st = self._lib.rri_resume(self._h, C.byref(done))
+        self._check(st)
+        return int(done.value)
+
+    def sweep(self, n_sweeps=1):
+        """n_sweeps Gauss-Seidel sweeps (nmf.py:415-476) on the device."""
+        done = C.c_int32(0)
+        return self._drive(self._lib.rri_sweep(self._h, int(n_sweeps), C.byref(done)), done)
+
+    def update_T_row(self, t):
+        st = self._lib.rri_update_T_row(self._h, int(t))
+        if st == _capi.RRI_PAUSED:
+            self._resolve_event()
+            st = self._lib.rri_resume(self._h, None)
+        self._check(st)
+
+    def update_W_col(self, t):
+        st = self._lib.rri_update_W_col(self._h, int(t))
+        if st == _capi.RRI_PAUSED:
+            self._resolve_event()
+            st = self._lib.rri_resume(self._h, None)
+        self._check(st)
+
+    # ---- around the loop ----------------------------------------------------------------
+    def project_W_rows(self, s):
+        if np.isscalar(s):
+            self._check(self._lib.rri_project_W_rows(self._h, float(s), None))
+        else:
+            v = np.ascontiguousarray(np.asarray(s, dtype=np.float64).ravel())
+            if v.size != self.n:
+                raise AssertionError('proj_mat_to_simplex: expected s to have size %d but s has size %d'
+                                     % (self.n, v.size))
+            self._check(self._lib.rri_project_W_rows(self._h, 0.0, v.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def objective(self):
+        out = C.c_double(0.0)
+        self._check(self._lib.rri_objective(self._h, C.byref(out)))
+        return float(out.value)
+
+    def objective_parts(self):
+        out = (C.c_double * 3)()
+        self._check(self._lib.rri_objective_parts(self._h, out))
+        return [float(v) for v in out]
+
+    def argmax_rows(self):
+        out = np.empty(self.n, dtype=np.int32)
+        self._check(self._lib.rri_argmax_rows(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def masked_rmse(self, I, J, vals, lo, hi):
+        ij = np.ascontiguousarray(np.stack([np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64)], 1))
+        v = np.ascontiguousarray(np.asarray(vals, dtype=np.float64))
+        out = C.c_double(0.0)
+        self._check(self._lib.rri_masked_rmse(self._h, ij.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              v.ctypes.data_as(C.POINTER(C.c_double)), v.size,
+                                              float(lo), float(hi), C.byref(out)))
+        return float(out.value)
+
+    def snapshot(self):
+        self._check(self._lib.rri_snapshot(self._h))
+
+    def rollback(self):
+        self._check(self._lib.rri_rollback(self._h))
+
+    # ---- row-sharded stepping -----------------------------------------------------------
+    def reduce_buffer(self):
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._check(self._lib.rri_reduce_buffer(self._h, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, int(cnt.value)
+
+    def bind_reduce_buffer(self, ptr, n_elems):
+        self._check(self._lib.rri_bind_reduce_buffer(self._h, C.c_void_p(ptr), int(n_elems)))
+
+    def topic_reduce_local(self, t):
+        self._check(self._lib.rri_topic_reduce_local(self._h, int(t)))
+
+    def topic_finish(self, t):
+        self._check(self._lib.rri_topic_finish(self._h, int(t)))
+
+    def poll(self):
+        return self._check(self._lib.rri_poll(self._h))
+
+    # ---- measurement --------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self._lib.rri_timing_enable(self._h, int(bool(on))))
+
+    def timing_read(self, kernel_id):
+        cnt, ms = C.c_int64(0), C.c_double(0.0)
+        self._check(self._lib.rri_timing_read(self._h, int(kernel_id), C.byref(cnt), C.byref(ms)))
+        return int(cnt.value), float(ms.value)
+
+    def synchronize(self):
+        self._check(self._lib.rri_synchronize(self._h))
+
+    def bench_rank1_update(self, reps=5):
+        ms = C.c_double(0.0)
+        self._check(self._lib.rri_bench_rank1_update(self._h, int(reps), C.byref(ms)))
+        return float(ms.value)
+
+    def bench_stream_copy(self, reps=5):
+        ms = C.c_double(0.0)
+        self._check(self._lib.rri_bench_stream_copy(self._h, int(reps), C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,223 @@
+"""GPU parity tests of the HIP RRI path, called through the C ABI (RRIEngine -> librri_hip.so),
+against (i) golden vectors captured from the unmodified reference and (ii) the CPU oracle on the
+same seeded inputs.
+
+Tolerances (relative Frobenius distance to the float64 reference result):
+    float64 path : 1e-10   (same algorithm, different summation order)
+    float32 path : 1e-4    (BASELINE.json north_star; measured values are ~1e-6..1e-5)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relfro
+from rri_nmf_amd.synthetic import planted_X, scaled_init
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float64: 1e-10, np.float32: 1e-4}
+
+
+def engine(*a, **kw):
+    from rri_nmf_amd.engine import RRIEngine
+    return RRIEngine(*a, **kw)
+
+
+def oracle():
+    from oracle import rri_oracle
+    return rri_oracle
+
+
+def run_engine(X, W0, T0, sweeps, dtype, final_proj=None, **params):
+    n, d = X.shape
+    k = W0.shape[1]
+    with engine(n, d, k, dtype=dtype) as e:
+        e.upload_X(X)
+        e.set_W(np.maximum(W0, 0))
+        e.set_T(np.maximum(T0, 0))
+        e.set_params(**params)
+        e.sweep(sweeps)
+        if final_proj is not None:
+            e.project_W_rows(final_proj)
+        return e.get_W(), e.get_T(), e.n_resets_used
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_plain_flavour_vs_reference_vectors(tag, dtype):
+    g = load_golden('g5_plain_' + tag)
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=0, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    for S in (1, 5, 30):
+        W, T, _ = run_engine(X, W0, T0, S, dtype)
+        assert relfro(W, g['W_s%d' % S]) < TOL[dtype], (S, relfro(W, g['W_s%d' % S]))
+        assert relfro(T, g['T_s%d' % S]) < TOL[dtype], (S, relfro(T, g['T_s%d' % S]))
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_sweeps_are_resumable(dtype):
+    """30 sweeps in one call == 30 calls of one sweep (carry across calls is exact)."""
+    g = load_golden('g5_plain_a')
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=0, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    with engine(n, d, k, dtype=dtype) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params()
+        for _ in range(30):
+            e.sweep(1)
+        W1, T1 = e.get_W(), e.get_T()
+    W2, T2, _ = run_engine(X, W0, T0, 30, dtype)
+    assert np.array_equal(W1, W2) and np.array_equal(T1, T2)
+    assert relfro(W1, g['W_s30']) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_topic_model_flavour(tag, dtype):
+    g = load_golden('g5_plain_' + tag)
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=0, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    orc = oracle()
+    Xn = orc.normalize(X.copy())
+    # nmf.py:875-878: T is projected once before the loop when project_T_each_iter
+    T0p = orc.proj_rows_simplex(np.maximum(T0, 0).copy(), 1.0)
+    for S in (1, 5):
+        W, T, _ = run_engine(Xn, W0, T0p, S, dtype, final_proj=1.0, project_T_each_iter=True,
+                             t_row_sum=1.0, w_row_sum=1.0)
+        assert relfro(W, g['tm_W_s%d' % S]) < TOL[dtype], relfro(W, g['tm_W_s%d' % S])
+        assert relfro(T, g['tm_T_s%d' % S]) < TOL[dtype], relfro(T, g['tm_T_s%d' % S])
+        assert np.abs(T.sum(1) - 1).max() < (1e-12 if dtype == np.float64 else 1e-5)
+        assert np.abs(W.sum(1) - 1).max() < (1e-12 if dtype == np.float64 else 1e-5)
+        assert W.min() >= 0 and T.min() >= 0
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_regularised_and_fixed_halves(dtype):
+    g = load_golden('g5_plain_a')
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=0, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    W, T, _ = run_engine(X, W0, T0, 5, dtype, reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03)
+    assert relfro(W, g['reg_W_s5']) < TOL[dtype] and relfro(T, g['reg_T_s5']) < TOL[dtype]
+    W, T, _ = run_engine(X, W0, T0, 3, dtype, fix_T=True)
+    assert relfro(W, g['fixT_W_s3']) < TOL[dtype] and relfro(T, np.maximum(T0, 0)) < 1e-7
+    W, T, _ = run_engine(X, W0, T0, 3, dtype, fix_W=True)
+    assert relfro(W, g['fixW_W_s3']) < TOL[dtype] and relfro(T, g['fixW_T_s3']) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_text_fixture_topic_assignments_are_exact(dtype):
+    """BASELINE north_star: bit-exact argmax topic assignments on the reference's fixture."""
+    g = load_golden('g1_tm_estimator')
+    X, W0, T0 = g['X'], g['W0'], g['T0']
+    for S in (1, 2, 10):
+        W, T, _ = run_engine(X, W0, T0, S, dtype, final_proj=1.0, project_T_each_iter=True,
+                             t_row_sum=1.0, w_row_sum=1.0)
+        assert relfro(W, g['W_s%d' % S]) < TOL[dtype] and relfro(T, g['T_s%d' % S]) < TOL[dtype]
+    assert np.array_equal(np.argmax(W, 1), g['argmax_s10'])
+    n, d = X.shape
+    with engine(n, d, 5, dtype=dtype) as e:
+        e.upload_X(X); e.set_W(W); e.set_T(T); e.set_params()
+        assert np.array_equal(e.argmax_rows(), g['argmax_s10'])
+    # fold-in of held-out documents (G2): fix_T, 4 sweeps, final projection
+    Wte, _, _ = run_engine(g['Xte'], g['Wte0'], g['T_s10'], 4, dtype, final_proj=1.0, fix_T=True,
+                           t_row_sum=1.0, w_row_sum=1.0)
+    assert relfro(Wte, g['Wte']) < TOL[dtype]
+    assert np.array_equal(np.argmax(Wte, 1), g['argmax_te'])
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_objective_matches_oracle(dtype):
+    orc = oracle()
+    X = planted_X(700, 333, 6, seed=5, dtype=np.float64)
+    W0, T0 = scaled_init(X, 6, seed=6)
+    with engine(700, 333, 6, dtype=dtype) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0)
+        e.set_params(reg_w_l1=0.3, reg_w_l2=0.1, reg_t_l1=0.4, reg_t_l2=0.2)
+        got = e.objective()
+    want = orc.true_objective(X, W0, T0, 0.1, 0.2, 0.3, 0.4)
+    assert abs(got - want) <= (1e-11 if dtype == np.float64 else 2e-6) * abs(want)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_rare_branches(dtype):
+    g = load_golden('g6_rare_branches')
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=3, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=4)
+    orc = oracle()
+    Xn = orc.normalize(X.copy())
+    T0p = orc.proj_rows_simplex(np.maximum(T0, 0).copy(), 1.0)
+    tol = TOL[dtype]
+    # T side c<=0 -> one-hot rows (optimization.py:68-70)
+    W, T, _ = run_engine(Xn, W0, T0p, 3, dtype, final_proj=1.0, project_T_each_iter=True, t_row_sum=1.0,
+                         w_row_sum=1.0, reg_t_l2=-50.0)
+    assert relfro(T, g['negT_T']) < tol and relfro(W, g['negT_W']) < tol
+    # W side c<=0 -> entries at ub (optimization.py:62-65)
+    W, T, _ = run_engine(Xn, W0, T0p, 2, dtype, project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0,
+                         reg_w_l2=-5.0)
+    assert relfro(T, g['negW_T']) < tol and relfro(W, g['negW_W']) < tol
+    Wd = g['dead_W0']
+    # dead column, no bound: unbounded (reference raises ValueError)
+    with pytest.raises(ValueError, match='unbounded'):
+        run_engine(X, Wd, T0, 2, dtype)
+    # dead column with ub: reset to the max-residual document (on the device)
+    W, T, nres = run_engine(X, Wd, T0, 2, dtype, t_row_sum=1.0)
+    assert nres >= 1 and relfro(T, g['dead_mrd_T']) < tol and relfro(W, g['dead_mrd_W']) < tol
+    # resets off / exhausted: the reference's assert
+    with pytest.raises(AssertionError, match='sums to 0'):
+        run_engine(X, Wd, T0, 2, dtype, t_row_sum=1.0, w_row_sum=1.0, reset_topic_method=None)
+    with pytest.raises(AssertionError, match='sums to 0'):
+        run_engine(X, Wd, T0, 2, dtype, t_row_sum=1.0, w_row_sum=1.0, n_resets=0)
+    with pytest.raises(ValueError, match='unbounded'):
+        run_engine(X, Wd, T0, 2, dtype, t_row_sum=1.0, reset_topic_method=None)
+    # every T row killed by a huge l1 penalty: 6 resets in one sweep
+    W, T, nres = run_engine(X, W0, T0, 1, dtype, t_row_sum=1.0, reg_t_l1=1e6)
+    assert nres == k and relfro(T, g['l1kill_T']) < tol and relfro(W, g['l1kill_W']) < tol
+    # W columns killed: max-residual resets from the W side
+    W, T, nres = run_engine(X, W0, T0, 1, dtype, t_row_sum=1.0, reg_w_l1=1e6)
+    assert nres == k and relfro(T, g['l1killW_mrd_T']) < tol and relfro(W, g['l1killW_mrd_W']) < tol
+    # ... and 'random' resets with the reference's seeding (numpy global RNG on the host)
+    W, T, nres = run_engine(X, W0, T0, 1, dtype, t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random',
+                            fix_reset_seed=True)
+    assert nres == k and relfro(T, g['l1killW_rnd_T']) < max(tol, 1e-7) and relfro(W, g['l1killW_rnd_W']) < max(tol, 1e-7)
+
+
+def test_ragged_shapes_float32():
+    """d not a multiple of the 16-byte vector, n not a multiple of any tile, k = 1, 2, 3."""
+    orc = oracle()
+    for (n, d, k) in [(37, 5, 1), (130, 1027, 2), (1000, 2051, 3), (65, 64, 7)]:
+        X = planted_X(n, d, max(k, 2), seed=11, dtype=np.float64)
+        W0, T0 = scaled_init(X, k, seed=12)
+        ref = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), max_iter=4, eps_stop=-1)
+        for dtype in (np.float64, np.float32):
+            W, T, _ = run_engine(X, W0, T0, 4, dtype)
+            assert relfro(W, ref['W']) < TOL[dtype] and relfro(T, ref['T']) < TOL[dtype], (n, d, k, dtype)
+
+
+def test_half_steps_match_a_sweep():
+    X = planted_X(300, 200, 4, seed=21, dtype=np.float64)
+    W0, T0 = scaled_init(X, 4, seed=22)
+    Wa, Ta, _ = run_engine(X, W0, T0, 2, np.float64)
+    with engine(300, 200, 4, dtype=np.float64) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params()
+        for _ in range(2):
+            for t in range(4):
+                e.update_T_row(t)
+                e.update_W_col(t)
+        Wb, Tb = e.get_W(), e.get_T()
+    assert relfro(Wb, Wa) < 1e-12 and relfro(Tb, Ta) < 1e-12
+
+
+def test_rank1_update_and_copy_bench_run():
+    X = planted_X(2048, 1024, 4, seed=1, dtype=np.float32)
+    W0, T0 = scaled_init(X, 4, seed=2)
+    with engine(2048, 1024, 4, dtype=np.float32) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params()
+        assert e.bench_rank1_update(3) > 0
+        assert e.bench_stream_copy(3) > 0
+        e.timing_enable(True)
+        e.sweep(2)
+        cnt, ms = e.timing_read(0)
+        assert cnt == 2 * 4 + 1 and ms > 0

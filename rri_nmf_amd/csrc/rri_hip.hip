@@ -3,8 +3,9 @@
 // Build (see __graft_entry__.build / rri_nmf_amd/build.py):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -Iinclude rri_nmf_amd/csrc/rri_hip.hip
 //
-// Data layout in HBM (one handle = one nmf() call = one row shard of one GPU):
-//   X     n x LD   row-major, LD = d rounded up to a 16-byte multiple, pad columns zero
+// Data layout in HBM (one handle = one nmf() call = one row shard of one GPU).  X (and the mask /
+// masked residual) are stored in the handle's dtype (fp32 or fp64); everything else is float64:
+//   X     n x LD   row-major, LD = d rounded up to a 16-byte multiple of X's type, pad columns zero
 //   W     n x k    row-major (as the reference); the active column is ALSO kept contiguous
 //                  in `wcol` (n) so the streaming pass reads it coalesced into LDS
 //   T     k x LD   row-major, pad columns zero
@@ -45,7 +46,7 @@ struct TimedLaunch {
 struct rri_ctx {
     i64 n = 0, d = 0, LD = 0;
     int k = 0, dtype = RRI_F32, weighted = 0, device = 0;
-    size_t es = 4;
+    size_t es = 4;  // element size of X / mask / residual; all other buffers are float64
     int VN = 4, PW = 1024;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -53,8 +54,8 @@ struct rri_ctx {
     void *X = nullptr, *M = nullptr, *E = nullptr;
     i64 ldx = 0, ldm = 0;
     bool own_X = false, own_M = false;
-    void *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
-    void *wcol = nullptr, *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Tt = nullptr;
+    double *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
+    double *wcol = nullptr, *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Tt = nullptr;
     bool own_red = false;
     i64 red_elems = 0;
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
@@ -166,51 +167,103 @@ struct TimedScope {
 };
 
 // ---- typed launch helpers ------------------------------------------------------------------
-template <typename S>
-struct Launch {
-    static size_t pass_shmem(const rri_ctx* c) { return 4 * 4 * 64 * 16 + 2 * (size_t)c->rpb * sizeof(S); }
+int g_pass_unroll = 4;  // rows in flight per wave in k_pass (env RRI_PASS_UNROLL: 2 or 4)
 
+// kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
+template <typename SX>
+struct LaunchX {
+    static size_t pass_shmem(const rri_ctx* c) {
+        return (size_t)4 * 4 * (16 / sizeof(SX)) * 64 * sizeof(double) + 2 * (size_t)c->rpb * sizeof(double);
+    }
+    template <bool DO_Y, bool DO_Z, bool UPD, int U>
+    static void pass_u(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b) {
+        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        typedef typename std::conditional<UPD, SX, const SX>::type XT;
+        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U>), dim3(c->npanels * c->nrb), dim3(256), pass_shmem(c),
+                           c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart, c->Zpart, c->LD,
+                           c->rpb, c->npanels, a, b, (const DevState*)c->st);
+    }
     template <bool DO_Y, bool DO_Z>
     static void pass(rri_ctx* c, int t) {
         TimedScope ts(c, 0);
-        const S* trow = (const S*)c->T + (i64)t * c->LD;
-        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
-        hipLaunchKernelGGL((k_pass<S, DO_Y, DO_Z, false>), dim3(c->npanels * c->nrb), dim3(256), pass_shmem(c),
-                           c->stream, (const S*)c->X, c->ldx, (int)c->n, ncols, trow, (const S*)c->wcol,
-                           (S*)c->Ypart, (S*)c->Zpart, c->LD, c->rpb, c->npanels, (const S*)nullptr,
-                           (const S*)nullptr, (const DevState*)c->st);
+        const double* trow = c->T + (i64)t * c->LD;
+        if (g_pass_unroll == 2) pass_u<DO_Y, DO_Z, false, 2>(c, c->X, trow, c->wcol, nullptr, nullptr);
+        else pass_u<DO_Y, DO_Z, false, 4>(c, c->X, trow, c->wcol, nullptr, nullptr);
     }
-    // R <- R - a b^T fused with the row dots (against trow) and column sums (against wcol) of the new R
-    static void rank1(rri_ctx* c, void* R, const void* a, const void* b, const void* trow, const void* wc) {
+    // R <- R - a b^T fused with the row dots (against trow) and column sums (against wc) of the new R
+    static void rank1(rri_ctx* c, void* R, const double* a, const double* b, const double* trow, const double* wc) {
         TimedScope ts(c, 3);
-        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
-        hipLaunchKernelGGL((k_pass<S, true, true, true>), dim3(c->npanels * c->nrb), dim3(256), pass_shmem(c),
-                           c->stream, (S*)R, c->ldx, (int)c->n, ncols, (const S*)trow, (const S*)wc, (S*)c->Ypart,
-                           (S*)c->Zpart, c->LD, c->rpb, c->npanels, (const S*)a, (const S*)b,
-                           (const DevState*)c->st);
+        if (g_pass_unroll == 2) pass_u<true, true, true, 2>(c, R, trow, wc, a, b);
+        else pass_u<true, true, true, 4>(c, R, trow, wc, a, b);
     }
+    static size_t resid_shmem(const rri_ctx* c) {
+        return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
+    }
+    static void resid(rri_ctx* c, bool masked, bool write_e, double* rowobj, double* rowpos) {
+        const unsigned nb = (unsigned)((c->n + 63) / 64);
+        const size_t sh = resid_shmem(c);
+#define RRI_RESID(MK, WE)                                                                                       \
+    hipLaunchKernelGGL((k_resid<SX, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const SX*)c->X, c->ldx,      \
+                       (const SX*)c->M, c->ldm, (const double*)c->W, (const double*)c->T, c->LD, (int)c->n,      \
+                       (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+        if (masked && write_e) RRI_RESID(true, true);
+        else if (masked) RRI_RESID(true, false);
+        else if (write_e) RRI_RESID(false, true);
+        else RRI_RESID(false, false);
+#undef RRI_RESID
+    }
+    static void reset_row(rri_ctx* c) {
+        hipLaunchKernelGGL((k_reset_row<SX>), dim3(c->ntb), dim3(256), 0, c->stream, (const SX*)c->X, c->ldx,
+                           (const double*)c->W, (const double*)c->T, c->LD, (int)c->d, c->k, (const i64*)c->itmp,
+                           c->xraw);
+    }
+    static hipError_t set_attrs() {
+        hipError_t e = hipSuccess;
+        const void* fns[] = {(const void*)k_resid<SX, true, true>, (const void*)k_resid<SX, true, false>,
+                             (const void*)k_resid<SX, false, true>, (const void*)k_resid<SX, false, false>};
+        for (const void* f : fns) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        return e;
+    }
+};
+
+#define DISPATCH(c, expr)                       \
+    do {                                        \
+        if ((c)->dtype == RRI_F32) {            \
+            typedef LaunchX<float> L;           \
+            expr;                               \
+        } else {                                \
+            typedef LaunchX<double> L;          \
+            expr;                               \
+        }                                       \
+    } while (0)
+
+struct LK {  // float64-only kernels
+    typedef double S;
     template <bool UPDATE, bool CARRY>
     static void wcol(rri_ctx* c, int t, int tn, int tx, int sweep) {
         TimedScope ts(c, 1);
         hipLaunchKernelGGL((k_wcol<S, UPDATE, CARRY>), dim3(c->nwb), dim3(c->RW), c->wcol_shmem, c->stream,
-                           (S*)c->W, (int)c->n, c->k, t, tn, tx, (const S*)c->Ypart, c->npanels, (const S*)c->Tt,
-                           (S*)c->wcol, c->Gpart, sweep, kparams(c), c->st);
+                           c->W, (int)c->n, c->k, t, tn, tx, (const S*)c->Ypart, c->npanels, (const S*)c->Tt,
+                           c->wcol, c->Gpart, sweep, kparams(c), c->st);
     }
     static void extract_col(rri_ctx* c, int col) {
         hipLaunchKernelGGL((k_extract_col<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                           (const S*)c->W, (int)c->n, c->k, col, (S*)c->wcol, (const DevState*)c->st);
+                           (const S*)c->W, (int)c->n, c->k, col, c->wcol, (const DevState*)c->st);
     }
     static void reduce(rri_ctx* c) {
         const int nb = (int)((c->LD + 255) / 256) + 1;
         hipLaunchKernelGGL((k_reduce<S>), dim3(nb), dim3(256), 0, c->stream, (const S*)c->Zpart, c->LD, c->nrb,
-                           (const double*)c->Gpart, c->nwb, c->k, (S*)c->red, (const DevState*)c->st);
+                           (const double*)c->Gpart, c->nwb, c->k, c->red, (const DevState*)c->st);
     }
     static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep) {
         hipLaunchKernelGGL((k_trow_numer<S>), dim3(c->ntb), dim3(256), 0, c->stream, (const S*)c->T, c->LD,
-                           (int)c->d, c->k, t, (const S*)c->red, c->LD, (S*)c->xraw, c->tpart, c->tpart_idx,
+                           (int)c->d, c->k, t, (const S*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx,
                            check_prev, tprev, sweep, kparams(c), c->st);
-        hipLaunchKernelGGL((k_trow_final<S>), dim3(1), dim3(1024), 0, c->stream, (S*)c->T, c->LD, (int)c->d, t,
-                           (S*)c->xraw, (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep,
+        hipLaunchKernelGGL((k_trow_final<S>), dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t,
+                           c->xraw, (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep,
                            kparams(c), c->st);
     }
     static void check_prev_only(rri_ctx* c, int tprev, int sweep, int pos) {
@@ -219,11 +272,11 @@ struct Launch {
     }
     static void tgram(rri_ctx* c, int t) {
         hipLaunchKernelGGL((k_tgram<S>), dim3(c->k), dim3(256), 0, c->stream, (const S*)c->T, c->LD, (int)c->d, t,
-                           (S*)c->Tt, c->st);
+                           c->Tt, c->st);
     }
     static void scale_wcol(rri_ctx* c, int t) {
         hipLaunchKernelGGL((k_scale_wcol<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                           (S*)c->W, (int)c->n, c->k, t, (const DevState*)c->st);
+                           c->W, (int)c->n, c->k, t, (const DevState*)c->st);
     }
     static void check_wcol(rri_ctx* c, int tprev, int sweep, int pos) {
         hipLaunchKernelGGL((k_check_wcol<S>), dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb,
@@ -231,42 +284,21 @@ struct Launch {
     }
     static void proj_rows(rri_ctx* c, double s, const double* svec) {
         const size_t sh = (size_t)c->RW * (c->k + 1) * sizeof(S);
-        hipLaunchKernelGGL((k_proj_rows<S>), dim3(c->nwb), dim3(c->RW), sh, c->stream, (S*)c->W, (int)c->n, c->k,
-                           s, svec);
+        hipLaunchKernelGGL((k_proj_rows<S>), dim3(c->nwb), dim3(c->RW), sh, c->stream, c->W, (int)c->n, c->k, s,
+                           svec);
     }
-    static size_t resid_shmem(const rri_ctx* c) {
-        return ((size_t)c->k * 64 + 32 * 64) * sizeof(S) + 64 * 17 * sizeof(double);
+    static void norms(rri_ctx* c, const double* A, i64 rows, i64 cols, i64 ld) {
+        hipLaunchKernelGGL((k_norms<S>), dim3(256), dim3(256), 0, c->stream, A, rows, cols, ld, c->normpart);
     }
-    static void resid(rri_ctx* c, bool masked, bool write_e, double* rowobj, double* rowpos) {
-        const unsigned nb = (unsigned)((c->n + 63) / 64);
-        const size_t sh = resid_shmem(c);
-#define RRI_RESID(MK, WE)                                                                                       \
-    hipLaunchKernelGGL((k_resid<S, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const S*)c->X, c->ldx,       \
-                       (const S*)c->M, c->ldm, (const S*)c->W, (const S*)c->T, c->LD, (int)c->n, (int)c->d,     \
-                       c->k, rowobj, rowpos, (S*)c->E, c->LD)
-        if (masked && write_e) RRI_RESID(true, true);
-        else if (masked) RRI_RESID(true, false);
-        else if (write_e) RRI_RESID(false, true);
-        else RRI_RESID(false, false);
-#undef RRI_RESID
-    }
-    static void norms(rri_ctx* c, const void* A, i64 rows, i64 cols, i64 ld) {
-        hipLaunchKernelGGL((k_norms<S>), dim3(256), dim3(256), 0, c->stream, (const S*)A, rows, cols, ld,
-                           c->normpart);
-    }
-    static void reset_row(rri_ctx* c, int t) {
-        hipLaunchKernelGGL((k_reset_row<S>), dim3(c->ntb), dim3(256), 0, c->stream, (const S*)c->X, c->ldx,
-                           (const S*)c->W, (const S*)c->T, c->LD, (int)c->d, c->k, (const i64*)c->itmp,
-                           (S*)c->xraw);
+    static void reset_commit(rri_ctx* c, int t) {
         const i64 m = std::max(c->n, c->d);
-        hipLaunchKernelGGL((k_reset_commit<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           (S*)c->W, (S*)c->T, c->LD, (int)c->n, (int)c->d, c->k, t, (const i64*)c->itmp,
-                           (const S*)c->xraw);
+        hipLaunchKernelGGL((k_reset_commit<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->W,
+                           c->T, c->LD, (int)c->n, (int)c->d, c->k, t, (const i64*)c->itmp, (const S*)c->xraw);
     }
     static void set_row_col(rri_ctx* c, int t, const double* trow, const double* wcolv) {
         const i64 m = std::max(c->n, c->d);
-        hipLaunchKernelGGL((k_set_row_col<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           (S*)c->W, (S*)c->T, c->LD, (int)c->n, (int)c->d, c->k, t, trow, wcolv);
+        hipLaunchKernelGGL((k_set_row_col<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->W,
+                           c->T, c->LD, (int)c->n, (int)c->d, c->k, t, trow, wcolv);
     }
     static void argmax_rows(rri_ctx* c, int* out) {
         hipLaunchKernelGGL((k_argmax_rows<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
@@ -278,17 +310,6 @@ struct Launch {
     }
 };
 
-#define DISPATCH(c, expr)                       \
-    do {                                        \
-        if ((c)->dtype == RRI_F32) {            \
-            typedef Launch<float> L;            \
-            expr;                               \
-        } else {                                \
-            typedef Launch<double> L;           \
-            expr;                               \
-        }                                       \
-    } while (0)
-
 // ---- upload / download with conversion -------------------------------------------------------
 template <typename Src, typename Dst>
 void launch_convert(rri_ctx* c, const void* src, i64 lds_, void* dst, i64 ldd, i64 rows, i64 cols) {
@@ -298,13 +319,15 @@ void launch_convert(rri_ctx* c, const void* src, i64 lds_, void* dst, i64 ldd, i
                        (Dst*)dst, ldd, rows, cols);
 }
 
-// host (rows x cols, stride ld, host_dtype) -> device (stride ldd, handle dtype)
+// host (rows x cols, stride ld, host_dtype) -> device (stride ldd, dev_dtype)
 rri_status to_device(rri_ctx* c, const void* host, i64 ld, int host_dtype, void* dev, i64 ldd, i64 rows,
-                     i64 cols) {
+                     i64 cols, int dev_dtype) {
     if (!host || ld < cols) return fail(c, RRI_ERR_INVALID, "bad host matrix (ld=%lld < cols=%lld)", ld, cols);
+    if (host_dtype != RRI_F32 && host_dtype != RRI_F64) return fail(c, RRI_ERR_INVALID, "bad host dtype");
     const size_t hs = host_dtype == RRI_F32 ? 4 : 8;
-    if (host_dtype == c->dtype) {
-        HIPCHK(c, hipMemcpy2DAsync(dev, ldd * c->es, host, ld * hs, cols * hs, rows, hipMemcpyHostToDevice,
+    const size_t ds = dev_dtype == RRI_F32 ? 4 : 8;
+    if (host_dtype == dev_dtype) {
+        HIPCHK(c, hipMemcpy2DAsync(dev, ldd * ds, host, ld * hs, cols * hs, rows, hipMemcpyHostToDevice,
                                    c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return RRI_OK;
@@ -323,11 +346,14 @@ rri_status to_device(rri_ctx* c, const void* host, i64 ld, int host_dtype, void*
     return RRI_OK;
 }
 
-rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int host_dtype, i64 rows, i64 cols) {
+rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int host_dtype, i64 rows, i64 cols,
+                   int dev_dtype) {
     if (!host || ld < cols) return fail(c, RRI_ERR_INVALID, "bad host matrix (ld=%lld < cols=%lld)", ld, cols);
+    if (host_dtype != RRI_F32 && host_dtype != RRI_F64) return fail(c, RRI_ERR_INVALID, "bad host dtype");
     const size_t hs = host_dtype == RRI_F32 ? 4 : 8;
-    if (host_dtype == c->dtype) {
-        HIPCHK(c, hipMemcpy2DAsync(host, ld * hs, dev, ldd * c->es, cols * hs, rows, hipMemcpyDeviceToHost,
+    const size_t ds = dev_dtype == RRI_F32 ? 4 : 8;
+    if (host_dtype == dev_dtype) {
+        HIPCHK(c, hipMemcpy2DAsync(host, ld * hs, dev, ldd * ds, cols * hs, rows, hipMemcpyDeviceToHost,
                                    c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return RRI_OK;
@@ -355,12 +381,12 @@ void invalidate(rri_ctx* c) {
 void enqueue_prologue(rri_ctx* c, int t, int sweep) {
     // the pending W-column check reads Gpart, which the prologue overwrites: resolve it first
     if (c->pending_wcheck) {
-        DISPATCH(c, L::check_wcol(c, c->pending_wcheck_topic, sweep, t));
+        LK::check_wcol(c, c->pending_wcheck_topic, sweep, t);
         c->pending_wcheck = false;
     }
-    DISPATCH(c, (L::template wcol<false, true>(c, t, t, t, sweep)));   // Gram row of w_t, wcol = W[:,t]
+    LK::wcol<false, true>(c, t, t, t, sweep);   // Gram row of w_t, wcol = W[:,t]
     DISPATCH(c, (L::template pass<false, true>(c, t)));               // w_t^T X
-    if (c->k > 1) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));     // next pass needs W[:,t+1]
+    if (c->k > 1) LK::extract_col(c, (t + 1) % c->k);     // next pass needs W[:,t+1]
     c->carry_valid = true;
     c->carry_topic = t;
 }
@@ -369,11 +395,11 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t) {
     if (!c->carry_valid || c->carry_topic != t) enqueue_prologue(c, t, sweep);
     {
         TimedScope ts(c, 2);
-        DISPATCH(c, L::reduce(c));
+        LK::reduce(c);
         const int chk = c->pending_wcheck ? 1 : 0;
-        DISPATCH(c, L::trow(c, t, chk, c->pending_wcheck_topic, sweep));
+        LK::trow(c, t, chk, c->pending_wcheck_topic, sweep);
         c->pending_wcheck = false;
-        if (c->prm.fix_W && no_regs(c)) DISPATCH(c, L::scale_wcol(c, t));
+        if (c->prm.fix_W && no_regs(c)) LK::scale_wcol(c, t);
     }
     c->carry_valid = false;
     c->resid_valid = false;
@@ -385,22 +411,22 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int tn = (t + 1) % k, tx = (t + 2) % k;
     {
         TimedScope ts(c, 2);
-        DISPATCH(c, L::tgram(c, t));
+        LK::tgram(c, t);
     }
     if (carry_next) {
         DISPATCH(c, (L::template pass<true, true>(c, t)));
-        DISPATCH(c, (L::template wcol<true, true>(c, t, tn, tx, sweep)));
+        LK::wcol<true, true>(c, t, tn, tx, sweep);
         c->carry_valid = true;
         c->carry_topic = tn;
         c->pending_wcheck = true;
         c->pending_wcheck_topic = t;
     } else {
         DISPATCH(c, (L::template pass<true, false>(c, t)));
-        DISPATCH(c, (L::template wcol<true, false>(c, t, tn, tx, sweep)));
+        LK::wcol<true, false>(c, t, tn, tx, sweep);
         // position of the NEXT step, where a resumed run continues
         int ns = sweep, np = t + 1;
         if (np == k) { np = 0; ns = sweep + 1; }
-        DISPATCH(c, L::check_wcol(c, t, ns, np));
+        LK::check_wcol(c, t, ns, np);
         c->carry_valid = false;
     }
     c->resid_valid = false;
@@ -417,7 +443,7 @@ void enqueue_from(rri_ctx* c, Cursor cur) {
         }
     }
     if (c->pending_wcheck) {  // last column of the call: report it in this call
-        DISPATCH(c, L::check_wcol(c, c->pending_wcheck_topic, c->run_total, 0));
+        LK::check_wcol(c, c->pending_wcheck_topic, c->run_total, 0);
         c->pending_wcheck = false;
     }
 }
@@ -524,10 +550,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     rpb = std::min<i64>(round_up(rpb, 16), 2048);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
+    if (const char* e = getenv("RRI_PASS_UNROLL")) g_pass_unroll = atoi(e) == 2 ? 2 : 4;
     // W-column kernel tile
     c->RW = 0;
     for (int rw : {256, 128, 64}) {
-        size_t sh = (40 + 4 * (size_t)k) * 8 + ((size_t)k + rw + (size_t)rw * (k + 1)) * c->es;
+        size_t sh = (40 + 4 * (size_t)k) * 8 + ((size_t)k + rw + (size_t)rw * (k + 1)) * 8;
         if (sh <= 64 * 1024 || rw == 64) { c->RW = rw; c->wcol_shmem = sh; break; }
     }
     if (c->wcol_shmem > 160 * 1024) {
@@ -539,19 +566,19 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->ntb = (int)((d + 255) / 256);
     c->red_elems = round_up(c->LD + k + 2, 4);
 
-    const size_t es = c->es;
-    CR(hipMalloc(&c->W, (size_t)n * k * es));
-    CR(hipMalloc(&c->T, (size_t)k * c->LD * es));
-    CR(hipMemsetAsync(c->T, 0, (size_t)k * c->LD * es, c->stream));
-    CR(hipMalloc(&c->wcol, (size_t)n * es));
-    CR(hipMalloc(&c->Ypart, (size_t)c->npanels * n * es));
-    CR(hipMalloc(&c->Zpart, (size_t)c->nrb * c->LD * es));
+    const size_t f8 = sizeof(double);
+    CR(hipMalloc((void**)&c->W, (size_t)n * k * f8));
+    CR(hipMalloc((void**)&c->T, (size_t)k * c->LD * f8));
+    CR(hipMemsetAsync(c->T, 0, (size_t)k * c->LD * f8, c->stream));
+    CR(hipMalloc((void**)&c->wcol, (size_t)n * f8));
+    CR(hipMalloc((void**)&c->Ypart, (size_t)c->npanels * n * f8));
+    CR(hipMalloc((void**)&c->Zpart, (size_t)c->nrb * c->LD * f8));
     CR(hipMalloc((void**)&c->Gpart, (size_t)c->nwb * (k + 2) * sizeof(double)));
-    CR(hipMalloc(&c->red, (size_t)c->red_elems * es));
-    CR(hipMemsetAsync(c->red, 0, (size_t)c->red_elems * es, c->stream));
+    CR(hipMalloc((void**)&c->red, (size_t)c->red_elems * f8));
+    CR(hipMemsetAsync(c->red, 0, (size_t)c->red_elems * f8, c->stream));
     c->own_red = true;
-    CR(hipMalloc(&c->xraw, (size_t)c->LD * es));
-    CR(hipMalloc(&c->Tt, (size_t)k * es));
+    CR(hipMalloc((void**)&c->xraw, (size_t)c->LD * f8));
+    CR(hipMalloc((void**)&c->Tt, (size_t)k * f8));
     CR(hipMalloc((void**)&c->tpart, (size_t)c->ntb * sizeof(double)));
     CR(hipMalloc((void**)&c->tpart_idx, (size_t)c->ntb * sizeof(i64)));
     CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
@@ -560,17 +587,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->st, sizeof(DevState)));
     CR(hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream));
     // opt in to large dynamic LDS where a kernel needs it
-    if (dtype == RRI_F32) {
-        CR(hipFuncSetAttribute((const void*)k_wcol<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CR(hipFuncSetAttribute((const void*)k_wcol<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CR(hipFuncSetAttribute((const void*)k_wcol<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CR(hipFuncSetAttribute((const void*)k_proj_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    } else {
-        CR(hipFuncSetAttribute((const void*)k_wcol<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CR(hipFuncSetAttribute((const void*)k_wcol<double, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CR(hipFuncSetAttribute((const void*)k_wcol<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CR(hipFuncSetAttribute((const void*)k_proj_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    CR(hipFuncSetAttribute((const void*)k_wcol<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CR(hipFuncSetAttribute((const void*)k_wcol<double, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CR(hipFuncSetAttribute((const void*)k_wcol<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CR(hipFuncSetAttribute((const void*)k_proj_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dtype == RRI_F32) CR(LaunchX<float>::set_attrs());
+    else CR(LaunchX<double>::set_attrs());
     CR(hipStreamSynchronize(c->stream));
 #undef CR
     *out = c;
@@ -583,9 +605,10 @@ rri_status rri_destroy(rri_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_X) (void)hipFree(c->X);
     if (c->own_M) (void)hipFree(c->M);
-    void* bufs[] = {c->E, c->W, c->T, c->Wprev, c->Tprev, c->wcol, c->Ypart, c->Zpart, c->xraw, c->Tt,
-                    c->Gpart, c->tpart, c->tpart_idx, c->rowobj, c->rowpos, c->normpart, c->dtmp, c->itmp,
-                    c->resetT, c->resetW, c->st};
+    void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev, (void*)c->wcol,
+                    (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Tt, (void*)c->Gpart,
+                    (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
+                    (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -608,7 +631,7 @@ rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_d
         if (c->LD != c->d) HIPCHK(c, hipMemsetAsync(c->X, 0, (size_t)c->n * c->LD * c->es, c->stream));
     }
     c->ldx = c->LD;
-    rri_status s = to_device(c, host, ld, host_dtype, c->X, c->ldx, c->n, c->d);
+    rri_status s = to_device(c, host, ld, host_dtype, c->X, c->ldx, c->n, c->d, c->dtype);
     if (s == RRI_OK) { c->have_X = true; invalidate(c); }
     return s;
 }
@@ -624,7 +647,7 @@ rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t hos
         if (c->LD != c->d) HIPCHK(c, hipMemsetAsync(c->M, 0, (size_t)c->n * c->LD * c->es, c->stream));
     }
     c->ldm = c->LD;
-    rri_status s = to_device(c, host, ld, host_dtype, c->M, c->ldm, c->n, c->d);
+    rri_status s = to_device(c, host, ld, host_dtype, c->M, c->ldm, c->n, c->d, c->dtype);
     if (s == RRI_OK) { c->have_M = true; invalidate(c); }
     return s;
 }
@@ -661,26 +684,26 @@ rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
 rri_status rri_set_W(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    rri_status s = to_device(c, host, ld, host_dtype, c->W, c->k, c->n, c->k);
+    rri_status s = to_device(c, host, ld, host_dtype, c->W, c->k, c->n, c->k, RRI_F64);
     if (s == RRI_OK) { c->have_W = true; invalidate(c); c->pending_wcheck = false; }
     return s;
 }
 rri_status rri_set_T(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    rri_status s = to_device(c, host, ld, host_dtype, c->T, c->LD, c->k, c->d);
+    rri_status s = to_device(c, host, ld, host_dtype, c->T, c->LD, c->k, c->d, RRI_F64);
     if (s == RRI_OK) { c->have_T = true; invalidate(c); }
     return s;
 }
 rri_status rri_get_W(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    return to_host(c, c->W, c->k, host, ld, host_dtype, c->n, c->k);
+    return to_host(c, c->W, c->k, host, ld, host_dtype, c->n, c->k, RRI_F64);
 }
 rri_status rri_get_T(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    return to_host(c, c->T, c->LD, host, ld, host_dtype, c->k, c->d);
+    return to_host(c, c->T, c->LD, host, ld, host_dtype, c->k, c->d, RRI_F64);
 }
 
 rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
@@ -755,7 +778,8 @@ rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen)
     DISPATCH(c, L::resid(c, false, false, nullptr, c->rowpos));
     hipLaunchKernelGGL(k_vec_sum_argmax, dim3(1), dim3(1024), 0, c->stream, (const double*)c->rowpos, c->n,
                        (double*)nullptr, c->itmp);
-    DISPATCH(c, L::reset_row(c, t));
+    DISPATCH(c, L::reset_row(c));
+    LK::reset_commit(c, t);
     i64 mi = -1;
     HIPCHK(c, hipMemcpyAsync(&mi, c->itmp, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -763,7 +787,7 @@ rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen)
     if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
     else invalidate(c);
     // a resumed W half needs the next active column in wcol
-    if (c->k > 1) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));
+    if (c->k > 1) LK::extract_col(c, (t + 1) % c->k);
     return RRI_OK;
 }
 
@@ -775,12 +799,12 @@ rri_status rri_apply_reset_vectors(rri_ctx* c, int32_t t, const double* T_row, c
     if (!c->resetW) HIPCHK(c, hipMalloc((void**)&c->resetW, (size_t)c->n * sizeof(double)));
     if (T_row) HIPCHK(c, hipMemcpyAsync(c->resetT, T_row, (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (W_col) HIPCHK(c, hipMemcpyAsync(c->resetW, W_col, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    DISPATCH(c, L::set_row_col(c, t, T_row ? c->resetT : nullptr, W_col ? c->resetW : nullptr));
+    LK::set_row_col(c, t, T_row ? c->resetT : nullptr, W_col ? c->resetW : nullptr);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
     else invalidate(c);
     HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
-    if (c->k > 1) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));
+    if (c->k > 1) LK::extract_col(c, (t + 1) % c->k);
     return RRI_OK;
 }
 
@@ -820,10 +844,10 @@ rri_status rri_update_W_col(rri_ctx* c, int32_t t) {
     r = clear_halt(c);
     if (r != RRI_OK) return r;
     // the half step must not depend on what an earlier call left in wcol
-    if (c->k > 1 && !c->prm.fix_T) DISPATCH(c, L::extract_col(c, (t + 1) % c->k));
+    if (c->k > 1 && !c->prm.fix_T) LK::extract_col(c, (t + 1) % c->k);
     enqueue_W_half(c, 0, t);
     if (c->pending_wcheck) {
-        DISPATCH(c, L::check_wcol(c, c->pending_wcheck_topic, 1, 0));
+        LK::check_wcol(c, c->pending_wcheck_topic, 1, 0);
         c->pending_wcheck = false;
     }
     DevState s;
@@ -843,7 +867,7 @@ rri_status rri_project_W_rows(rri_ctx* c, double s, const double* s_vec) {
         HIPCHK(c, hipMalloc((void**)&dvec, (size_t)c->n * sizeof(double)));
         HIPCHK(c, hipMemcpyAsync(dvec, s_vec, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
-    DISPATCH(c, L::proj_rows(c, s, dvec));
+    LK::proj_rows(c, s, dvec);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (dvec) (void)hipFree(dvec);
     invalidate(c);
@@ -851,8 +875,8 @@ rri_status rri_project_W_rows(rri_ctx* c, double s, const double* s_vec) {
     return RRI_OK;
 }
 
-static rri_status norms_of(rri_ctx* c, const void* A, i64 rows, i64 cols, i64 ld, double out[3]) {
-    DISPATCH(c, L::norms(c, A, rows, cols, ld));
+static rri_status norms_of(rri_ctx* c, const double* A, i64 rows, i64 cols, i64 ld, double out[3]) {
+    LK::norms(c, A, rows, cols, ld);
     double h[256 * 3];
     HIPCHK(c, hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -904,7 +928,7 @@ rri_status rri_argmax_rows(rri_ctx* c, int32_t* out_host) {
     HIPCHK(c, hipSetDevice(c->device));
     int* dev = nullptr;
     HIPCHK(c, hipMalloc((void**)&dev, (size_t)c->n * sizeof(int)));
-    DISPATCH(c, L::argmax_rows(c, dev));
+    LK::argmax_rows(c, dev);
     hipError_t e = hipMemcpyAsync(out_host, dev, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(dev);
@@ -928,7 +952,7 @@ rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, in
     if (e == hipSuccess) e = hipMemcpyAsync(dv, vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream);
     double h[256];
     if (e == hipSuccess) {
-        DISPATCH(c, L::masked_sqerr(c, dij, dv, count, lo, hi));
+        LK::masked_sqerr(c, dij, dv, count, lo, hi);
         e = hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -944,10 +968,10 @@ rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, in
 rri_status rri_snapshot(rri_ctx* c) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->Wprev) HIPCHK(c, hipMalloc(&c->Wprev, (size_t)c->n * c->k * c->es));
-    if (!c->Tprev) HIPCHK(c, hipMalloc(&c->Tprev, (size_t)c->k * c->LD * c->es));
-    HIPCHK(c, hipMemcpyAsync(c->Wprev, c->W, (size_t)c->n * c->k * c->es, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->Tprev, c->T, (size_t)c->k * c->LD * c->es, hipMemcpyDeviceToDevice, c->stream));
+    if (!c->Wprev) HIPCHK(c, hipMalloc((void**)&c->Wprev, (size_t)c->n * c->k * 8));
+    if (!c->Tprev) HIPCHK(c, hipMalloc((void**)&c->Tprev, (size_t)c->k * c->LD * 8));
+    HIPCHK(c, hipMemcpyAsync(c->Wprev, c->W, (size_t)c->n * c->k * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->Tprev, c->T, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
     return RRI_OK;
 }
 
@@ -955,8 +979,8 @@ rri_status rri_rollback(rri_ctx* c) {
     CHECK_CTX(c);
     if (!c->Wprev || !c->Tprev) return fail(c, RRI_ERR_INVALID, "no snapshot taken");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->W, c->Wprev, (size_t)c->n * c->k * c->es, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->T, c->Tprev, (size_t)c->k * c->LD * c->es, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->W, c->Wprev, (size_t)c->n * c->k * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->T, c->Tprev, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate(c);
     c->pending_wcheck = false;
@@ -966,7 +990,7 @@ rri_status rri_rollback(rri_ctx* c) {
 // ---- row-sharded multi-GPU ---------------------------------------------------------------------------------
 rri_status rri_reduce_buffer(rri_ctx* c, void** dev_ptr, int64_t* n_elems) {
     CHECK_CTX(c);
-    if (dev_ptr) *dev_ptr = c->red;
+    if (dev_ptr) *dev_ptr = (void*)c->red;
     if (n_elems) *n_elems = c->red_elems;
     return RRI_OK;
 }
@@ -976,7 +1000,7 @@ rri_status rri_bind_reduce_buffer(rri_ctx* c, void* dev_ptr, int64_t n_elems) {
     if (!dev_ptr || n_elems < c->red_elems || ((uintptr_t)dev_ptr) % 16)
         return fail(c, RRI_ERR_INVALID, "reduce buffer needs >= %lld elements, 16-byte aligned", c->red_elems);
     if (c->own_red && c->red) (void)hipFree(c->red);
-    c->red = dev_ptr;
+    c->red = (double*)dev_ptr;
     c->own_red = false;
     invalidate(c);
     return RRI_OK;
@@ -1000,7 +1024,7 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
         c->pending_wcheck_topic = pt;
         if (pend) return fail(c, RRI_ERR_INVALID, "carry lost while a sharded column check was pending");
     }
-    DISPATCH(c, L::reduce(c));
+    LK::reduce(c);
     return RRI_OK;
 }
 
@@ -1009,14 +1033,14 @@ rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     HIPCHK(c, hipSetDevice(c->device));
     if (t < 0) {  // only the pending column check, against the (all-reduced) buffer
         if (c->pending_wcheck) {
-            DISPATCH(c, L::check_prev_only(c, c->pending_wcheck_topic, 0, 0));
+            LK::check_prev_only(c, c->pending_wcheck_topic, 0, 0);
             c->pending_wcheck = false;
         }
         return RRI_OK;
     }
     if (t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     const int chk = c->pending_wcheck ? 1 : 0;
-    DISPATCH(c, L::trow(c, t, chk, c->pending_wcheck_topic, 0));
+    LK::trow(c, t, chk, c->pending_wcheck_topic, 0);
     c->pending_wcheck = false;
     c->carry_valid = false;
     enqueue_W_half(c, 0, t);
@@ -1102,11 +1126,12 @@ rri_status rri_bench_rank1_update(rri_ctx* c, int32_t reps, double* avg_ms) {
     // scratch residual R = copy of X; a = wcol-shaped vector, b = a T row (values are irrelevant to timing,
     // tiny magnitudes keep R finite over the repetitions)
     const size_t bytes = (size_t)c->n * c->ldx * c->es;
-    void *R = nullptr, *a = nullptr;
+    void* R = nullptr;
+    double* a = nullptr;
     HIPCHK(c, hipMalloc(&R, bytes));
-    if (hipMalloc(&a, (size_t)c->n * c->es) != hipSuccess) { (void)hipFree(R); return fail(c, RRI_ERR_HIP, "hipMalloc failed"); }
+    if (hipMalloc((void**)&a, (size_t)c->n * 8) != hipSuccess) { (void)hipFree(R); return fail(c, RRI_ERR_HIP, "hipMalloc failed"); }
     (void)hipMemcpyAsync(R, c->X, bytes, hipMemcpyDeviceToDevice, c->stream);
-    (void)hipMemsetAsync(a, 0, (size_t)c->n * c->es, c->stream);
+    (void)hipMemsetAsync(a, 0, (size_t)c->n * 8, c->stream);
     (void)hipMemsetAsync(c->st, 0, 16, c->stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);

@@ -15,6 +15,12 @@
 //   k_pass        the X pass (HBM-bound, the roofline kernel)
 //   k_wcol        numer_W = X t - W (T t)_{-t} - reg ; qf_min ; writes W[:,t];
 //                 Gram row / norm partials of the NEXT topic                             (nmf.py:464-469,673-676)
+// Precision: X (and the mask / masked residual) live in HBM in the handle's storage type SX
+// (fp32 or fp64).  EVERYTHING else -- W, T, partial sums, the closed-form updates -- is float64:
+// the streaming pass converts each loaded X element and accumulates with v_fma_f64.  The pass is
+// HBM-bound with the vector ALU ~85 % idle, so float64 arithmetic costs no time, X traffic is
+// unchanged, and the result follows the reference's float64 numpy to summation-order rounding
+// instead of the ~1e-4 an fp32 accumulation gives on these iterations.
 // Rare branches (reset conditions, unbounded problems, dead columns) set DevState::halt;
 // every later kernel of the queue then returns at once and the host resolves the event.
 #pragma once
@@ -53,28 +59,48 @@ struct KParams {
 //   panel (PW = 64 lanes * 16 B * NCH) of one row block; its waves take rows round-robin.
 //   Per row a wave issues NCH 16-byte loads per lane (coalesced 1 KiB each), keeps U rows in
 //   flight, holds the active T-row slice (DO_Y) and the column-sum accumulators (DO_Z) in
-//   registers, and reads the active W-column entries from LDS.
-// =========================================================================================
+//   registers (float64), and reads the active W-column entries from LDS.
 //   UPD: the explicit-residual form north_star names: X is the residual R and the pass first
 //   applies the rank-one update R <- R - a b^T (a from LDS, b slice in registers), writes R back
 //   and takes the row dots / column sums of the UPDATED residual in the same sweep over memory.
-template <typename S, bool DO_Y, bool DO_Z, bool UPD>
-__global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, S, const S>::type* __restrict__ X,
+// =========================================================================================
+template <typename SX> struct XVec;
+template <> struct XVec<float> {
+    typedef float4 type;
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const float4& v, double (&o)[4]) {
+        o[0] = (double)v.x; o[1] = (double)v.y; o[2] = (double)v.z; o[3] = (double)v.w;
+    }
+    static __device__ __forceinline__ float4 pack(const double (&o)[4]) {
+        return make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+    }
+    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct XVec<double> {
+    typedef double2 type;
+    static constexpr int N = 2;
+    static __device__ __forceinline__ void unpack(const double2& v, double (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+    static __device__ __forceinline__ double2 pack(const double (&o)[2]) { return make_double2(o[0], o[1]); }
+    static __device__ __forceinline__ double2 zero() { return make_double2(0.0, 0.0); }
+};
+
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD, int U>
+__global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX, const SX>::type* __restrict__ X,
                                               i64 ldx, int n, int ncols,
-                                              const S* __restrict__ trow, const S* __restrict__ wcol,
-                                              S* __restrict__ Ypart, S* __restrict__ Zpart, i64 ldz,
-                                              int rpb, int npanels, const S* __restrict__ avec,
-                                              const S* __restrict__ bvec, const DevState* __restrict__ st) {
-    typedef typename V16<S>::type V;
-    constexpr int VN = V16<S>::N;
+                                              const double* __restrict__ trow, const double* __restrict__ wcol,
+                                              double* __restrict__ Ypart, double* __restrict__ Zpart, i64 ldz,
+                                              int rpb, int npanels, const double* __restrict__ avec,
+                                              const double* __restrict__ bvec, const DevState* __restrict__ st) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;
     constexpr int NCH = 4;
-    constexpr int U = 4;
     constexpr int PW = 64 * VN * NCH;
     if (st->halt) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    V* zsh = reinterpret_cast<V*>(smem);                                  // [4][NCH*64]
-    S* wsh = reinterpret_cast<S*>(smem + 4 * NCH * 64 * sizeof(V));       // [rpb]
-    S* ash = wsh + rpb;                                                   // [rpb] (UPD)
+    double* zsh = reinterpret_cast<double*>(smem);            // [4 waves][NCH][VN][64]
+    double* wsh = zsh + 4 * NCH * VN * 64;                    // [rpb]
+    double* ash = wsh + rpb;                                  // [rpb] (UPD)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int panel = blockIdx.x % npanels;
@@ -90,16 +116,17 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, S, 
         __syncthreads();
     }
     bool ok[NCH];
-    V tv[NCH], zacc[NCH], bv[NCH];
+    double tv[NCH][VN], zacc[NCH][VN], bv[NCH][VN];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = colb + c * 64 * VN;
         ok[c] = col < ncols;
-        tv[c] = vzero((V*)0);
-        zacc[c] = vzero((V*)0);
-        bv[c] = vzero((V*)0);
-        if (DO_Y && ok[c]) tv[c] = *reinterpret_cast<const V*>(trow + col);
-        if (UPD && ok[c]) bv[c] = *reinterpret_cast<const V*>(bvec + col);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            zacc[c][e] = 0.0;
+            tv[c][e] = (DO_Y && ok[c]) ? trow[col + e] : 0.0;
+            bv[c][e] = (UPD && ok[c]) ? bvec[col + e] : 0.0;
+        }
     }
     const bool full = (panel + 1) * PW <= ncols;  // wave-uniform: no column predication needed
 
@@ -109,45 +136,53 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, S, 
         for (int u = 0; u < U; ++u) {
             const int rr = r + 4 * u;
             if (rr < row1) {
-                const S* xp = X + (i64)rr * ldx + colb;
+                const SX* xp = X + (i64)rr * ldx + colb;
                 if (full) {
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) x[u][c] = *reinterpret_cast<const V*>(xp + c * 64 * VN);
                 } else {
 #pragma unroll
                     for (int c = 0; c < NCH; ++c)
-                        x[u][c] = ok[c] ? *reinterpret_cast<const V*>(xp + c * 64 * VN) : vzero((V*)0);
+                        x[u][c] = ok[c] ? *reinterpret_cast<const V*>(xp + c * 64 * VN) : XV::zero();
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) x[u][c] = vzero((V*)0);
+                for (int c = 0; c < NCH; ++c) x[u][c] = XV::zero();
             }
         }
-        S ys[U];
+        double ys[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int rr = r + 4 * u;
-            S wv = S(0);
+            double wv = 0.0, na = 0.0;
             if (DO_Z && rr < row1) wv = wsh[rr - row0];
-            if constexpr (UPD) if (rr < row1) {
-                const S na = -ash[rr - row0];
-                S* xo = X + (i64)rr * ldx + colb;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    vaxpy(x[u][c], na, bv[c]);
-                    if (full || ok[c]) *reinterpret_cast<V*>(xo + c * 64 * VN) = x[u][c];
-                }
-            }
-            S yp = S(0);
+            if (UPD && rr < row1) na = -ash[rr - row0];
+            double yp = 0.0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (DO_Y) yp = vdot(x[u][c], tv[c], yp);
-                if (DO_Z) vaxpy(zacc[c], wv, x[u][c]);
+                double xe[VN];
+                XV::unpack(x[u][c], xe);
+                if constexpr (UPD) {
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) xe[e] = fma(na, bv[c][e], xe[e]);
+                    if (rr < row1 && (full || ok[c]))
+                        *reinterpret_cast<V*>(X + (i64)rr * ldx + colb + c * 64 * VN) = XV::pack(xe);
+                    if constexpr (sizeof(SX) == 4) {
+                        // the stored residual is what later passes read: use the ROUNDED values
+                        const V rounded = XV::pack(xe);
+                        XV::unpack(rounded, xe);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    if (DO_Y) yp = fma(xe[e], tv[c][e], yp);
+                    if (DO_Z) zacc[c][e] = fma(wv, xe[e], zacc[c][e]);
+                }
             }
-            if (DO_Y) ys[u] = wave_sum<S>(yp);
+            if (DO_Y) ys[u] = wave_sum<double>(yp);
         }
         if (DO_Y) {
-            S yv = ys[0];
+            double yv = ys[0];
 #pragma unroll
             for (int u = 1; u < U; ++u)
                 if (lane == u) yv = ys[u];
@@ -156,16 +191,20 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, S, 
         }
     }
     if (DO_Z) {
+        // cross-wave sum through LDS; layout [wave][c][e][lane] keeps the b64 accesses conflict-free
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) zsh[(wave * NCH + c) * 64 + lane] = zacc[c];
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) zsh[((wave * NCH + c) * VN + e) * 64 + lane] = zacc[c][e];
         __syncthreads();
-        const int tid = threadIdx.x;
-        V s = zsh[tid];
-        vadd(s, zsh[256 + tid]);
-        vadd(s, zsh[512 + tid]);
-        vadd(s, zsh[768 + tid]);
-        const int col = panel * PW + (tid >> 6) * 64 * VN + (tid & 63) * VN;
-        if (col < ldz) *reinterpret_cast<V*>(Zpart + (i64)rb * ldz + col) = s;
+        constexpr int PER_WAVE = NCH * VN * 64;  // doubles per wave image == columns of the panel
+        for (int q = threadIdx.x; q < PER_WAVE; q += 256) {   // q = column inside the panel (coalesced store)
+            const int c = q / (64 * VN), ln = (q % (64 * VN)) / VN, e = q % VN;
+            const int li = (c * VN + e) * 64 + ln;
+            const double s = (zsh[li] + zsh[PER_WAVE + li]) + (zsh[2 * PER_WAVE + li] + zsh[3 * PER_WAVE + li]);
+            const int col = panel * PW + q;
+            if (col < ldz) Zpart[(i64)rb * ldz + col] = s;
+        }
     }
 }
 
@@ -566,11 +605,12 @@ __global__ __launch_bounds__(256) void k_proj_rows(S* __restrict__ W, int n, int
 //   - WRITE_E: the masked residual M .* E of the weighted flavour.
 // grid = ceil(n/64) workgroups of 256; each walks all column tiles (deterministic sums).
 // =========================================================================================
-template <typename S, bool MASKED, bool WRITE_E>
-__global__ __launch_bounds__(256) void k_resid(const S* __restrict__ X, i64 ldx, const S* __restrict__ M, i64 ldm,
-                                               const S* __restrict__ W, const S* __restrict__ T, i64 ldt,
+template <typename SX, bool MASKED, bool WRITE_E>
+__global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M, i64 ldm,
+                                               const double* __restrict__ W, const double* __restrict__ T, i64 ldt,
                                                int n, int d, int k, double* __restrict__ rowobj,
-                                               double* __restrict__ rowpos, S* __restrict__ E, i64 lde) {
+                                               double* __restrict__ rowpos, SX* __restrict__ E, i64 lde) {
+    typedef double S;
     constexpr int KC = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     S* Wsh = reinterpret_cast<S*>(smem);          // [k][64]  (transposed tile of W)
@@ -617,9 +657,9 @@ __global__ __launch_bounds__(256) void k_resid(const S* __restrict__ X, i64 ldx,
             for (int b = 0; b < 4; ++b) {
                 const i64 j = c0 + tx * 4 + b;
                 if (j >= d) continue;
-                S e = X[i * ldx + j] - acc[a][b];
-                const S m = MASKED ? M[i * ldm + j] : S(1);
-                if (WRITE_E) E[i * lde + j] = m * e;
+                S e = (S)X[i * ldx + j] - acc[a][b];
+                const S m = MASKED ? (S)M[i * ldm + j] : S(1);
+                if (WRITE_E) E[i * lde + j] = (SX)(m * e);
                 so[a] += (double)m * (double)e * (double)e;
                 const double ep = e > S(0) ? (double)e : 0.0;
                 sp[a] += ep * ep;
@@ -686,16 +726,17 @@ __global__ __launch_bounds__(1024) void k_vec_sum_argmax(const double* __restric
 }
 
 // 'max_resid_document' reset, step 1: row = max(X[mi,:] - W[mi,:] T, 0) (nmf.py:771,774)
-template <typename S>
-__global__ __launch_bounds__(256) void k_reset_row(const S* __restrict__ X, i64 ldx, const S* __restrict__ W,
-                                                   const S* __restrict__ T, i64 ldt, int d, int k,
-                                                   const i64* __restrict__ mi_ptr, S* __restrict__ rowout) {
+template <typename SX>
+__global__ __launch_bounds__(256) void k_reset_row(const SX* __restrict__ X, i64 ldx, const double* __restrict__ W,
+                                                   const double* __restrict__ T, i64 ldt, int d, int k,
+                                                   const i64* __restrict__ mi_ptr, double* __restrict__ rowout) {
+    typedef double S;
     const i64 mi = *mi_ptr;
     const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
     if (j >= d) return;
     S acc = S(0);
     for (int l = 0; l < k; ++l) acc = fma(W[mi * k + l], T[(i64)l * ldt + j], acc);
-    rowout[j] = fmax(X[mi * ldx + j] - acc, S(0));
+    rowout[j] = fmax((S)X[mi * ldx + j] - acc, S(0));
 }
 // step 2: T[t,:] = row ; W[:,t] = e_mi (nmf.py:774-776)
 template <typename S>

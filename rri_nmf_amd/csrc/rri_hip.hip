@@ -6,8 +6,8 @@
 // Data layout in HBM (one handle = one nmf() call = one row shard of one GPU).  X (and the mask /
 // masked residual) are stored in the handle's dtype (fp32 or fp64); everything else is float64:
 //   X     n x LD   row-major, LD = d rounded up to a 16-byte multiple of X's type, pad columns zero
-//   W     n x k    row-major (as the reference); the active column is ALSO kept contiguous
-//                  in `wcol` (n) so the streaming pass reads it coalesced into LDS
+//   Wt    k x n    k-major (W transposed): column t of W is the contiguous row Wt[t,:], so the
+//                  streaming pass stages the active column into LDS with coalesced loads
 //   T     k x LD   row-major, pad columns zero
 //   Ypart npanels x n      per-column-panel partial row dots of the pass
 //   Zpart nrb x LD         per-row-block partial column sums of the pass
@@ -55,7 +55,9 @@ struct rri_ctx {
     i64 ldx = 0, ldm = 0;
     bool own_X = false, own_M = false;
     double *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
-    double *wcol = nullptr, *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Tt = nullptr;
+    double *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Ttpart = nullptr;
+    i64 ldw = 0;     // row stride of the k-major W (>= n)
+    int nsplit = 4;  // column slices of k_tgram
     bool own_red = false;
     i64 red_elems = 0;
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
@@ -65,8 +67,7 @@ struct rri_ctx {
     double *resetT = nullptr, *resetW = nullptr;  // staging for 'random' reset vectors
     DevState* st = nullptr;
 
-    int npanels = 1, rpb = 1, nrb = 1, RW = 256, nwb = 1, ntb = 1;
-    size_t wcol_shmem = 0;
+    int npanels = 1, rpb = 1, nrb = 1, nwb = 1, ntb = 1;
 
     rri_params prm{};
     bool have_params = false, have_X = false, have_W = false, have_T = false, have_M = false;
@@ -183,12 +184,14 @@ struct LaunchX {
                            c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart, c->Zpart, c->LD,
                            c->rpb, c->npanels, a, b, (const DevState*)c->st);
     }
+    // row dots against T[t,:] (DO_Y) and column sums against W[:,tz] (DO_Z)
     template <bool DO_Y, bool DO_Z>
-    static void pass(rri_ctx* c, int t) {
+    static void pass(rri_ctx* c, int t, int tz) {
         TimedScope ts(c, 0);
         const double* trow = c->T + (i64)t * c->LD;
-        if (g_pass_unroll == 2) pass_u<DO_Y, DO_Z, false, 2>(c, c->X, trow, c->wcol, nullptr, nullptr);
-        else pass_u<DO_Y, DO_Z, false, 4>(c, c->X, trow, c->wcol, nullptr, nullptr);
+        const double* wc = c->W + (i64)tz * c->ldw;
+        if (g_pass_unroll == 2) pass_u<DO_Y, DO_Z, false, 2>(c, c->X, trow, wc, nullptr, nullptr);
+        else pass_u<DO_Y, DO_Z, false, 4>(c, c->X, trow, wc, nullptr, nullptr);
     }
     // R <- R - a b^T fused with the row dots (against trow) and column sums (against wc) of the new R
     static void rank1(rri_ctx* c, void* R, const double* a, const double* b, const double* trow, const double* wc) {
@@ -204,8 +207,8 @@ struct LaunchX {
         const size_t sh = resid_shmem(c);
 #define RRI_RESID(MK, WE)                                                                                       \
     hipLaunchKernelGGL((k_resid<SX, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const SX*)c->X, c->ldx,      \
-                       (const SX*)c->M, c->ldm, (const double*)c->W, (const double*)c->T, c->LD, (int)c->n,      \
-                       (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+                       (const SX*)c->M, c->ldm, (const double*)c->W, c->ldw, (const double*)c->T, c->LD,       \
+                       (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
         if (masked && write_e) RRI_RESID(true, true);
         else if (masked) RRI_RESID(true, false);
         else if (write_e) RRI_RESID(false, true);
@@ -213,9 +216,9 @@ struct LaunchX {
 #undef RRI_RESID
     }
     static void reset_row(rri_ctx* c) {
-        hipLaunchKernelGGL((k_reset_row<SX>), dim3(c->ntb), dim3(256), 0, c->stream, (const SX*)c->X, c->ldx,
-                           (const double*)c->W, (const double*)c->T, c->LD, (int)c->d, c->k, (const i64*)c->itmp,
-                           c->xraw);
+        hipLaunchKernelGGL((k_reset_row<SX>), dim3((unsigned)((c->d + 255) / 256)), dim3(256), 0, c->stream,
+                           (const SX*)c->X, c->ldx, (const double*)c->W, c->ldw, (const double*)c->T, c->LD,
+                           (int)c->d, c->k, (const i64*)c->itmp, c->xraw);
     }
     static hipError_t set_attrs() {
         hipError_t e = hipSuccess;
@@ -241,92 +244,87 @@ struct LaunchX {
     } while (0)
 
 struct LK {  // float64-only kernels
-    typedef double S;
+    static size_t wcol_shmem(const rri_ctx* c) { return (size_t)(4 * (c->k + 2) + c->k) * sizeof(double); }
     template <bool UPDATE, bool CARRY>
-    static void wcol(rri_ctx* c, int t, int tn, int tx, int sweep) {
+    static void wcol(rri_ctx* c, int t, int tn, int sweep) {
         TimedScope ts(c, 1);
-        hipLaunchKernelGGL((k_wcol<S, UPDATE, CARRY>), dim3(c->nwb), dim3(c->RW), c->wcol_shmem, c->stream,
-                           c->W, (int)c->n, c->k, t, tn, tx, (const S*)c->Ypart, c->npanels, (const S*)c->Tt,
-                           c->wcol, c->Gpart, sweep, kparams(c), c->st);
-    }
-    static void extract_col(rri_ctx* c, int col) {
-        hipLaunchKernelGGL((k_extract_col<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                           (const S*)c->W, (int)c->n, c->k, col, c->wcol, (const DevState*)c->st);
+        hipLaunchKernelGGL((k_wcol<UPDATE, CARRY>), dim3(c->nwb), dim3(256), wcol_shmem(c), c->stream, c->W, c->ldw,
+                           (int)c->n, c->k, t, tn, (const double*)c->Ypart, c->npanels, (const double*)c->Ttpart,
+                           c->nsplit, c->Gpart, sweep, kparams(c), c->st);
     }
     static void reduce(rri_ctx* c) {
-        const int nb = (int)((c->LD + 255) / 256) + 1;
-        hipLaunchKernelGGL((k_reduce<S>), dim3(nb), dim3(256), 0, c->stream, (const S*)c->Zpart, c->LD, c->nrb,
+        const int nb = (int)((c->LD + 31) / 32) + 1;
+        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
                            (const double*)c->Gpart, c->nwb, c->k, c->red, (const DevState*)c->st);
     }
     static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep) {
-        hipLaunchKernelGGL((k_trow_numer<S>), dim3(c->ntb), dim3(256), 0, c->stream, (const S*)c->T, c->LD,
-                           (int)c->d, c->k, t, (const S*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx,
-                           check_prev, tprev, sweep, kparams(c), c->st);
-        hipLaunchKernelGGL((k_trow_final<S>), dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t,
-                           c->xraw, (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep,
+        hipLaunchKernelGGL(k_trow_numer, dim3(c->ntb), dim3(128), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
+                           (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, check_prev, tprev, sweep,
                            kparams(c), c->st);
+        hipLaunchKernelGGL(k_trow_final, dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t, c->xraw,
+                           (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep, kparams(c), c->st);
     }
     static void check_prev_only(rri_ctx* c, int tprev, int sweep, int pos) {
-        hipLaunchKernelGGL((k_check_red<S>), dim3(1), dim3(64), 0, c->stream, (const S*)c->red, c->LD, c->k, tprev,
+        hipLaunchKernelGGL(k_check_red, dim3(1), dim3(64), 0, c->stream, (const double*)c->red, c->LD, c->k, tprev,
                            sweep, pos, kparams(c), c->st);
     }
     static void tgram(rri_ctx* c, int t) {
-        hipLaunchKernelGGL((k_tgram<S>), dim3(c->k), dim3(256), 0, c->stream, (const S*)c->T, c->LD, (int)c->d, t,
-                           c->Tt, c->st);
+        hipLaunchKernelGGL(k_tgram, dim3(c->k, c->nsplit), dim3(256), 0, c->stream, (const double*)c->T, c->LD,
+                           (int)c->d, c->k, t, c->Ttpart, (const DevState*)c->st);
     }
     static void scale_wcol(rri_ctx* c, int t) {
-        hipLaunchKernelGGL((k_scale_wcol<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                           c->W, (int)c->n, c->k, t, (const DevState*)c->st);
+        hipLaunchKernelGGL(k_scale_wcol, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->W,
+                           c->ldw, (int)c->n, t, (const DevState*)c->st);
     }
     static void check_wcol(rri_ctx* c, int tprev, int sweep, int pos) {
-        hipLaunchKernelGGL((k_check_wcol<S>), dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb,
-                           c->k, tprev, sweep, pos, kparams(c), c->st);
+        hipLaunchKernelGGL(k_check_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb, c->k,
+                           tprev, sweep, pos, kparams(c), c->st);
     }
     static void proj_rows(rri_ctx* c, double s, const double* svec) {
-        const size_t sh = (size_t)c->RW * (c->k + 1) * sizeof(S);
-        hipLaunchKernelGGL((k_proj_rows<S>), dim3(c->nwb), dim3(c->RW), sh, c->stream, c->W, (int)c->n, c->k, s,
+        hipLaunchKernelGGL(k_proj_rows, dim3(c->nwb), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, c->k, s,
                            svec);
     }
     static void norms(rri_ctx* c, const double* A, i64 rows, i64 cols, i64 ld) {
-        hipLaunchKernelGGL((k_norms<S>), dim3(256), dim3(256), 0, c->stream, A, rows, cols, ld, c->normpart);
+        hipLaunchKernelGGL(k_norms, dim3(256), dim3(256), 0, c->stream, A, rows, cols, ld, c->normpart);
     }
     static void reset_commit(rri_ctx* c, int t) {
         const i64 m = std::max(c->n, c->d);
-        hipLaunchKernelGGL((k_reset_commit<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->W,
-                           c->T, c->LD, (int)c->n, (int)c->d, c->k, t, (const i64*)c->itmp, (const S*)c->xraw);
+        hipLaunchKernelGGL(k_reset_commit, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->W, c->ldw,
+                           c->T, c->LD, (int)c->n, (int)c->d, t, (const i64*)c->itmp, (const double*)c->xraw);
     }
     static void set_row_col(rri_ctx* c, int t, const double* trow, const double* wcolv) {
         const i64 m = std::max(c->n, c->d);
-        hipLaunchKernelGGL((k_set_row_col<S>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->W,
-                           c->T, c->LD, (int)c->n, (int)c->d, c->k, t, trow, wcolv);
+        hipLaunchKernelGGL(k_set_row_col, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->W, c->ldw,
+                           c->T, c->LD, (int)c->n, (int)c->d, t, trow, wcolv);
     }
     static void argmax_rows(rri_ctx* c, int* out) {
-        hipLaunchKernelGGL((k_argmax_rows<S>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                           (const S*)c->W, (int)c->n, c->k, out);
+        hipLaunchKernelGGL(k_argmax_rows, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)c->W, c->ldw, (int)c->n, c->k, out);
     }
     static void masked_sqerr(rri_ctx* c, const i64* ij, const double* vals, i64 count, double lo, double hi) {
-        hipLaunchKernelGGL((k_masked_sqerr<S>), dim3(256), dim3(256), 0, c->stream, (const S*)c->W,
-                           (const S*)c->T, c->LD, c->k, ij, vals, count, lo, hi, c->normpart);
+        hipLaunchKernelGGL(k_masked_sqerr, dim3(256), dim3(256), 0, c->stream, (const double*)c->W, c->ldw,
+                           (const double*)c->T, c->LD, c->k, ij, vals, count, lo, hi, c->normpart);
     }
 };
 
 // ---- upload / download with conversion -------------------------------------------------------
-template <typename Src, typename Dst>
+template <typename Src, typename Dst, bool TR>
 void launch_convert(rri_ctx* c, const void* src, i64 lds_, void* dst, i64 ldd, i64 rows, i64 cols) {
     const i64 total = rows * cols;
     const unsigned nb = (unsigned)std::min<i64>(4096, (total + 255) / 256);
-    hipLaunchKernelGGL((k_convert2d<Src, Dst>), dim3(nb ? nb : 1), dim3(256), 0, c->stream, (const Src*)src, lds_,
-                       (Dst*)dst, ldd, rows, cols);
+    hipLaunchKernelGGL((k_convert2d<Src, Dst, TR>), dim3(nb ? nb : 1), dim3(256), 0, c->stream, (const Src*)src,
+                       lds_, (Dst*)dst, ldd, rows, cols);
 }
 
-// host (rows x cols, stride ld, host_dtype) -> device (stride ldd, dev_dtype)
+// host (rows x cols, stride ld, host_dtype) -> device (stride ldd, dev_dtype).
+// transpose: the device image is cols x rows (dst[c][r] = host[r][c]).
 rri_status to_device(rri_ctx* c, const void* host, i64 ld, int host_dtype, void* dev, i64 ldd, i64 rows,
-                     i64 cols, int dev_dtype) {
+                     i64 cols, int dev_dtype, bool transpose = false) {
     if (!host || ld < cols) return fail(c, RRI_ERR_INVALID, "bad host matrix (ld=%lld < cols=%lld)", ld, cols);
     if (host_dtype != RRI_F32 && host_dtype != RRI_F64) return fail(c, RRI_ERR_INVALID, "bad host dtype");
     const size_t hs = host_dtype == RRI_F32 ? 4 : 8;
     const size_t ds = dev_dtype == RRI_F32 ? 4 : 8;
-    if (host_dtype == dev_dtype) {
+    if (host_dtype == dev_dtype && !transpose) {
         HIPCHK(c, hipMemcpy2DAsync(dev, ldd * ds, host, ld * hs, cols * hs, rows, hipMemcpyHostToDevice,
                                    c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -337,8 +335,17 @@ rri_status to_device(rri_ctx* c, const void* host, i64 ld, int host_dtype, void*
     hipError_t e = hipMemcpy2DAsync(tmp, cols * hs, host, ld * hs, cols * hs, rows, hipMemcpyHostToDevice,
                                     c->stream);
     if (e == hipSuccess) {
-        if (host_dtype == RRI_F32) launch_convert<float, double>(c, tmp, cols, dev, ldd, rows, cols);
-        else launch_convert<double, float>(c, tmp, cols, dev, ldd, rows, cols);
+        const bool hf = host_dtype == RRI_F32, df = dev_dtype == RRI_F32;
+#define RRI_CONV(SRC, DST)                                                                  \
+    do {                                                                                    \
+        if (transpose) launch_convert<SRC, DST, true>(c, tmp, cols, dev, ldd, rows, cols);  \
+        else launch_convert<SRC, DST, false>(c, tmp, cols, dev, ldd, rows, cols);           \
+    } while (0)
+        if (hf && df) RRI_CONV(float, float);
+        else if (hf) RRI_CONV(float, double);
+        else if (df) RRI_CONV(double, float);
+        else RRI_CONV(double, double);
+#undef RRI_CONV
         e = hipStreamSynchronize(c->stream);
     }
     (void)hipFree(tmp);
@@ -346,13 +353,14 @@ rri_status to_device(rri_ctx* c, const void* host, i64 ld, int host_dtype, void*
     return RRI_OK;
 }
 
+// device (dev_dtype, stride ldd) -> host rows x cols.  transpose: the device image is cols x rows.
 rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int host_dtype, i64 rows, i64 cols,
-                   int dev_dtype) {
+                   int dev_dtype, bool transpose = false) {
     if (!host || ld < cols) return fail(c, RRI_ERR_INVALID, "bad host matrix (ld=%lld < cols=%lld)", ld, cols);
     if (host_dtype != RRI_F32 && host_dtype != RRI_F64) return fail(c, RRI_ERR_INVALID, "bad host dtype");
     const size_t hs = host_dtype == RRI_F32 ? 4 : 8;
     const size_t ds = dev_dtype == RRI_F32 ? 4 : 8;
-    if (host_dtype == dev_dtype) {
+    if (host_dtype == dev_dtype && !transpose) {
         HIPCHK(c, hipMemcpy2DAsync(host, ld * hs, dev, ldd * ds, cols * hs, rows, hipMemcpyDeviceToHost,
                                    c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -360,8 +368,20 @@ rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int
     }
     void* tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, (size_t)rows * cols * hs));
-    if (host_dtype == RRI_F32) launch_convert<double, float>(c, dev, ldd, tmp, cols, rows, cols);
-    else launch_convert<float, double>(c, dev, ldd, tmp, cols, rows, cols);
+    {
+        const bool hf = host_dtype == RRI_F32, df = dev_dtype == RRI_F32;
+        // source is the device image; for a transposed image its shape is cols x rows
+#define RRI_CONV(SRC, DST)                                                                     \
+    do {                                                                                       \
+        if (transpose) launch_convert<SRC, DST, true>(c, dev, ldd, tmp, cols, cols, rows);     \
+        else launch_convert<SRC, DST, false>(c, dev, ldd, tmp, cols, rows, cols);              \
+    } while (0)
+        if (df && hf) RRI_CONV(float, float);
+        else if (df) RRI_CONV(float, double);
+        else if (hf) RRI_CONV(double, float);
+        else RRI_CONV(double, double);
+#undef RRI_CONV
+    }
     hipError_t e = hipMemcpy2DAsync(host, ld * hs, tmp, cols * hs, cols * hs, rows, hipMemcpyDeviceToHost,
                                     c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -377,16 +397,15 @@ void invalidate(rri_ctx* c) {
 }
 
 // ---- the topic-step scheduler ------------------------------------------------------------------
-// carry := Zpart/Gpart hold the partial sums of topic `carry_topic` AND wcol holds column carry_topic+1.
+// carry := Zpart/Gpart hold the partial sums of topic `carry_topic`.
 void enqueue_prologue(rri_ctx* c, int t, int sweep) {
     // the pending W-column check reads Gpart, which the prologue overwrites: resolve it first
     if (c->pending_wcheck) {
         LK::check_wcol(c, c->pending_wcheck_topic, sweep, t);
         c->pending_wcheck = false;
     }
-    LK::wcol<false, true>(c, t, t, t, sweep);   // Gram row of w_t, wcol = W[:,t]
-    DISPATCH(c, (L::template pass<false, true>(c, t)));               // w_t^T X
-    if (c->k > 1) LK::extract_col(c, (t + 1) % c->k);     // next pass needs W[:,t+1]
+    LK::wcol<false, true>(c, t, t, sweep);                             // Gram row of w_t
+    DISPATCH(c, (L::template pass<false, true>(c, t, t)));            // w_t^T X
     c->carry_valid = true;
     c->carry_topic = t;
 }
@@ -408,21 +427,21 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t) {
 void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int k = c->k;
     const bool carry_next = (k > 1) && !c->prm.fix_T;
-    const int tn = (t + 1) % k, tx = (t + 2) % k;
+    const int tn = (t + 1) % k;
     {
         TimedScope ts(c, 2);
         LK::tgram(c, t);
     }
     if (carry_next) {
-        DISPATCH(c, (L::template pass<true, true>(c, t)));
-        LK::wcol<true, true>(c, t, tn, tx, sweep);
+        DISPATCH(c, (L::template pass<true, true>(c, t, tn)));
+        LK::wcol<true, true>(c, t, tn, sweep);
         c->carry_valid = true;
         c->carry_topic = tn;
         c->pending_wcheck = true;
         c->pending_wcheck_topic = t;
     } else {
-        DISPATCH(c, (L::template pass<true, false>(c, t)));
-        LK::wcol<true, false>(c, t, tn, tx, sweep);
+        DISPATCH(c, (L::template pass<true, false>(c, t, tn)));
+        LK::wcol<true, false>(c, t, tn, sweep);
         // position of the NEXT step, where a resumed run continues
         int ns = sweep, np = t + 1;
         if (np == k) { np = 0; ns = sweep + 1; }
@@ -546,31 +565,22 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     i64 rpb = (n + nrb_t - 1) / nrb_t;
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
+    if (const char* e = getenv("RRI_PASS_UNROLL")) g_pass_unroll = atoi(e) == 2 ? 2 : 4;
     rpb = std::max<i64>(rpb, rpb_min);
     rpb = std::min<i64>(round_up(rpb, 16), 2048);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
     if (const char* e = getenv("RRI_PASS_UNROLL")) g_pass_unroll = atoi(e) == 2 ? 2 : 4;
-    // W-column kernel tile
-    c->RW = 0;
-    for (int rw : {256, 128, 64}) {
-        size_t sh = (40 + 4 * (size_t)k) * 8 + ((size_t)k + rw + (size_t)rw * (k + 1)) * 8;
-        if (sh <= 64 * 1024 || rw == 64) { c->RW = rw; c->wcol_shmem = sh; break; }
-    }
-    if (c->wcol_shmem > 160 * 1024) {
-        fail(nullptr, RRI_ERR_UNSUPPORTED, "k=%d needs more LDS than one CU has", k);
-        rri_destroy(c);
-        return RRI_ERR_UNSUPPORTED;
-    }
-    c->nwb = (int)((n + c->RW - 1) / c->RW);
-    c->ntb = (int)((d + 255) / 256);
+    c->nwb = (int)((n + 255) / 256);
+    c->ntb = (int)((d + 127) / 128);
+    c->ldw = n;
+    c->nsplit = (int)std::max<i64>(1, std::min<i64>(8, d / 2048));
     c->red_elems = round_up(c->LD + k + 2, 4);
 
     const size_t f8 = sizeof(double);
-    CR(hipMalloc((void**)&c->W, (size_t)n * k * f8));
+    CR(hipMalloc((void**)&c->W, (size_t)k * c->ldw * f8));
     CR(hipMalloc((void**)&c->T, (size_t)k * c->LD * f8));
     CR(hipMemsetAsync(c->T, 0, (size_t)k * c->LD * f8, c->stream));
-    CR(hipMalloc((void**)&c->wcol, (size_t)n * f8));
     CR(hipMalloc((void**)&c->Ypart, (size_t)c->npanels * n * f8));
     CR(hipMalloc((void**)&c->Zpart, (size_t)c->nrb * c->LD * f8));
     CR(hipMalloc((void**)&c->Gpart, (size_t)c->nwb * (k + 2) * sizeof(double)));
@@ -578,7 +588,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMemsetAsync(c->red, 0, (size_t)c->red_elems * f8, c->stream));
     c->own_red = true;
     CR(hipMalloc((void**)&c->xraw, (size_t)c->LD * f8));
-    CR(hipMalloc((void**)&c->Tt, (size_t)k * f8));
+    CR(hipMalloc((void**)&c->Ttpart, (size_t)c->nsplit * k * f8));
     CR(hipMalloc((void**)&c->tpart, (size_t)c->ntb * sizeof(double)));
     CR(hipMalloc((void**)&c->tpart_idx, (size_t)c->ntb * sizeof(i64)));
     CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
@@ -587,10 +597,6 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->st, sizeof(DevState)));
     CR(hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream));
     // opt in to large dynamic LDS where a kernel needs it
-    CR(hipFuncSetAttribute((const void*)k_wcol<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CR(hipFuncSetAttribute((const void*)k_wcol<double, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CR(hipFuncSetAttribute((const void*)k_wcol<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CR(hipFuncSetAttribute((const void*)k_proj_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (dtype == RRI_F32) CR(LaunchX<float>::set_attrs());
     else CR(LaunchX<double>::set_attrs());
     CR(hipStreamSynchronize(c->stream));
@@ -605,8 +611,7 @@ rri_status rri_destroy(rri_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_X) (void)hipFree(c->X);
     if (c->own_M) (void)hipFree(c->M);
-    void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev, (void*)c->wcol,
-                    (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Tt, (void*)c->Gpart,
+    void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st};
     for (void* b : bufs)
@@ -684,7 +689,7 @@ rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
 rri_status rri_set_W(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    rri_status s = to_device(c, host, ld, host_dtype, c->W, c->k, c->n, c->k, RRI_F64);
+    rri_status s = to_device(c, host, ld, host_dtype, c->W, c->ldw, c->n, c->k, RRI_F64, true);
     if (s == RRI_OK) { c->have_W = true; invalidate(c); c->pending_wcheck = false; }
     return s;
 }
@@ -698,7 +703,7 @@ rri_status rri_set_T(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtyp
 rri_status rri_get_W(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    return to_host(c, c->W, c->k, host, ld, host_dtype, c->n, c->k, RRI_F64);
+    return to_host(c, c->W, c->ldw, host, ld, host_dtype, c->n, c->k, RRI_F64, true);
 }
 rri_status rri_get_T(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
@@ -764,9 +769,6 @@ static void event_resolved(rri_ctx* c) {
     c->pending.kind = RRI_EVENT_NONE;
     if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
     invalidate(c);
-    if (c->resume_at.phase == 1) {
-        // resuming at the W half of topic t: the pass needs wcol = W[:,t+1] (untouched by the reset of column t)
-    }
 }
 
 rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen) {
@@ -786,8 +788,6 @@ rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen)
     if (row_chosen) *row_chosen = mi;
     if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
     else invalidate(c);
-    // a resumed W half needs the next active column in wcol
-    if (c->k > 1) LK::extract_col(c, (t + 1) % c->k);
     return RRI_OK;
 }
 
@@ -804,7 +804,6 @@ rri_status rri_apply_reset_vectors(rri_ctx* c, int32_t t, const double* T_row, c
     if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
     else invalidate(c);
     HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
-    if (c->k > 1) LK::extract_col(c, (t + 1) % c->k);
     return RRI_OK;
 }
 
@@ -843,8 +842,6 @@ rri_status rri_update_W_col(rri_ctx* c, int32_t t) {
     c->run_total = 1;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
-    // the half step must not depend on what an earlier call left in wcol
-    if (c->k > 1 && !c->prm.fix_T) LK::extract_col(c, (t + 1) % c->k);
     enqueue_W_half(c, 0, t);
     if (c->pending_wcheck) {
         LK::check_wcol(c, c->pending_wcheck_topic, 1, 0);
@@ -898,7 +895,7 @@ rri_status rri_objective_parts(rri_ctx* c, double out[3]) {
     HIPCHK(c, hipMemcpyAsync(&base, c->dtmp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double nw[3];
-    rri_status r = norms_of(c, c->W, c->n, c->k, c->k, nw);
+    rri_status r = norms_of(c, c->W, c->k, c->n, c->ldw, nw);
     if (r != RRI_OK) return r;
     out[0] = 0.5 * base;
     out[1] = nw[1];
@@ -968,9 +965,9 @@ rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, in
 rri_status rri_snapshot(rri_ctx* c) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->Wprev) HIPCHK(c, hipMalloc((void**)&c->Wprev, (size_t)c->n * c->k * 8));
+    if (!c->Wprev) HIPCHK(c, hipMalloc((void**)&c->Wprev, (size_t)c->k * c->ldw * 8));
     if (!c->Tprev) HIPCHK(c, hipMalloc((void**)&c->Tprev, (size_t)c->k * c->LD * 8));
-    HIPCHK(c, hipMemcpyAsync(c->Wprev, c->W, (size_t)c->n * c->k * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->Wprev, c->W, (size_t)c->k * c->ldw * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->Tprev, c->T, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
     return RRI_OK;
 }
@@ -979,7 +976,7 @@ rri_status rri_rollback(rri_ctx* c) {
     CHECK_CTX(c);
     if (!c->Wprev || !c->Tprev) return fail(c, RRI_ERR_INVALID, "no snapshot taken");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->W, c->Wprev, (size_t)c->n * c->k * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->W, c->Wprev, (size_t)c->k * c->ldw * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->T, c->Tprev, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate(c);

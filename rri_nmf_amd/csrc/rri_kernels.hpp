@@ -209,32 +209,35 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
 }
 
 // =========================================================================================
-// k_wcol: W-column update of topic t (UPDATE) and Gram-row / norm partials + contiguous copy
-// of the column tx the next pass streams against (CARRY).  blockDim = RW rows (64/128/256); the RW x k tile of
-// W is staged in LDS (coalesced global reads, conflict-free row reads with stride k+1).
-// Gpart[b][0..k) = sum_i wn_i W[i,:], [k] = sum wn_i^2, [k+1] = sum_i W[i,t] (new).
+// W is stored k-major on the device (Wt: k x ldw, ldw >= n): column t of W is the contiguous
+// row Wt[t,:], so the pass reads the active column coalesced and k_wcol needs no LDS staging.
+//
+// k_wcol: W-column update of topic t (UPDATE) and the Gram row w_tn^T W / ||w_tn||^2 of the NEXT
+// topic tn (CARRY), one thread per row of W.  Gpart[b][0..k) = sum_i wn_i W[i,:], [k] = sum wn_i^2,
+// [k+1] = sum_i W[i,t] (new).  T T[t]^T arrives as nsplit partial vectors from k_tgram.
 // =========================================================================================
-template <typename S, bool UPDATE, bool CARRY>
-__global__ __launch_bounds__(256) void k_wcol(S* __restrict__ W, int n, int k, int t, int tn, int tx, const S* __restrict__ Ypart,
-                       int npanels, const S* __restrict__ Tt, S* __restrict__ wcol,
-                       double* __restrict__ Gpart, int sweep, KParams p, DevState* st) {
+template <bool UPDATE, bool CARRY>
+__global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, int n, int k, int t, int tn,
+                                              const double* __restrict__ Ypart, int npanels,
+                                              const double* __restrict__ Ttpart, int nsplit,
+                                              double* __restrict__ Gpart, int sweep, KParams p, DevState* st) {
     if (st->halt) return;
-    const int RW = blockDim.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* scratch = reinterpret_cast<double*>(smem);                 // 40 doubles
-    double* gsh = scratch + 40;                                        // [4][k]
-    S* tts = reinterpret_cast<S*>(gsh + 4 * k);                        // [k]
-    S* wnsh = tts + k;                                                 // [RW]
-    S* wt = wnsh + RW;                                                 // [RW][k+1]
-    const int kp = k + 1;
-    const i64 row0 = (i64)blockIdx.x * RW;
-    const int rows_here = (int)min((i64)RW, (i64)n - row0);
-
+    double* gsh = reinterpret_cast<double*>(smem);   // [4][k+2]
+    double* tts = gsh + 4 * (k + 2);                 // [k]
     double cden = 0.0;
     int mode = 0;
     if (UPDATE) {
-        cden = st->nt + p.reg_w_l2;  // denom = nt + reg_w_l2 (nmf.py:465)
+        for (int l = tid; l < k; l += 256) {
+            double a = 0.0;
+            for (int q = 0; q < nsplit; ++q) a += Ttpart[q * k + l];
+            tts[l] = a;                               // entry t holds ||T[t,:]||^2 until zeroed below
+        }
+        __syncthreads();
+        cden = tts[t] + p.reg_w_l2;                   // denom = nt + reg_w_l2 (nmf.py:465)
+        __syncthreads();
+        if (tid == 0) tts[t] = 0.0;                   // Tt[t] = 0 (nmf.py:732)
         if (!(cden > 0.0)) {
             // scalar c<=0 with s=None (optimization.py:60-67): entries jump to ub, or unbounded
             if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;
@@ -245,84 +248,87 @@ __global__ __launch_bounds__(256) void k_wcol(S* __restrict__ W, int n, int k, i
                 return;
             }
         }
-        for (int l = tid; l < k; l += RW) tts[l] = Tt[l];
+        __syncthreads();
     }
-    for (int idx = tid; idx < RW * k; idx += RW) {
-        const int r = idx / k, l = idx - r * k;
-        wt[r * kp + l] = (idx < rows_here * k) ? W[row0 * k + idx] : S(0);
-    }
-    __syncthreads();
-    const bool valid = tid < rows_here;
-    const i64 i = row0 + tid;
-    S wnew = S(0);
-    if (UPDATE && valid) {
-        S y = S(0);
+    const i64 i = (i64)blockIdx.x * 256 + tid;
+    const bool valid = i < n;
+    double y = 0.0;
+    if (UPDATE && valid)
         for (int q = 0; q < npanels; ++q) y += Ypart[(i64)q * n + i];
-        S dotv = S(0);
-        for (int l = 0; l < k; ++l) dotv = fma(wt[tid * kp + l], tts[l], dotv);
-        const S numer = (y - dotv) - (S)p.reg_w_l1;
-        if (mode == 0) wnew = fmax(numer, S(0)) / ((S)cden + (S)p.eps);
-        else wnew = ((double)(-numer) + cden < 0.0) ? (S)p.w_row_sum : S(0);
-        wt[tid * kp + t] = wnew;
-        W[i * k + t] = wnew;
-    }
-    S wnv = S(0);
-    if (CARRY) {
-        // Gram row of the NEXT topic tn; the pass after next needs column tx contiguous
-        if (valid) { wnv = wt[tid * kp + tn]; wcol[i] = wt[tid * kp + tx]; }
-        wnsh[tid] = wnv;
-    }
-    __syncthreads();
-    if (CARRY) {
-        const int g = tid >> 6, l0 = tid & 63;
-        for (int l = l0; l < k; l += 64) {
-            double acc = 0.0;
-            for (int r = g * 64; r < g * 64 + 64; ++r) acc += (double)wnsh[r] * (double)wt[r * kp + l];
-            gsh[g * k + l] = acc;
+    const double wn = (CARRY && valid) ? Wt[(i64)tn * ldw + i] : 0.0;
+    double dotv = 0.0;
+    for (int l = 0; l < k; ++l) {
+        const double wl = (valid && !(UPDATE && l == t)) ? Wt[(i64)l * ldw + i] : 0.0;
+        if (UPDATE) dotv = fma(wl, tts[l], dotv);
+        if (CARRY) {
+            const double g = wave_sum<double>(wn * wl);
+            if (lane == 0) gsh[wave * (k + 2) + l] = g;
         }
     }
-    const double nwp = block_sum(CARRY ? (double)wnv * (double)wnv : 0.0, scratch);
-    const double swp = block_sum(UPDATE ? (double)wnew : 0.0, scratch);  // also orders gsh writes
-    double* gp = Gpart + (i64)blockIdx.x * (k + 2);
-    const int ng = RW >> 6;
-    for (int l = tid; l < k; l += RW) {
-        double a = 0.0;
-        if (CARRY) for (int g = 0; g < ng; ++g) a += gsh[g * k + l];
-        gp[l] = a;
+    double wnew = 0.0;
+    if (UPDATE && valid) {
+        const double numer = (y - dotv) - p.reg_w_l1;
+        if (mode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
+        else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
+        Wt[(i64)t * ldw + i] = wnew;
     }
-    if (tid == 0) { gp[k] = nwp; gp[k + 1] = swp; }
+    {
+        const double gt = wave_sum<double>(wn * wnew);
+        const double nwp = wave_sum<double>(wn * wn);
+        const double swp = wave_sum<double>(wnew);
+        if (lane == 0) {
+            if (UPDATE && CARRY) gsh[wave * (k + 2) + t] = gt;
+            gsh[wave * (k + 2) + k] = nwp;
+            gsh[wave * (k + 2) + k + 1] = swp;
+            if (!CARRY) for (int l = 0; l < k; ++l) gsh[wave * (k + 2) + l] = 0.0;
+        }
+    }
+    __syncthreads();
+    double* gp = Gpart + (i64)blockIdx.x * (k + 2);
+    for (int l = tid; l < k + 2; l += 256)
+        gp[l] = (gsh[l] + gsh[(k + 2) + l]) + (gsh[2 * (k + 2) + l] + gsh[3 * (k + 2) + l]);
 }
 
 // =========================================================================================
 // k_reduce: fixed-order reduction of the row-block partials into the reduce buffer
 //   red[0..ldz) = w^T X ; red[ldz..ldz+k) = w^T W ; red[ldz+k] = ||w||^2 ; red[ldz+k+1] = sum W[:,tprev]
 // (in the row-sharded multi-GPU run this buffer is what the ranks all-reduce).
+// 1024 threads: column blocks take 32 columns x 32 row-block groups, the last block the Gram row.
 // =========================================================================================
-template <typename S>
-__global__ __launch_bounds__(256) void k_reduce(const S* __restrict__ Zpart, i64 ldz, int nrb,
-                                                const double* __restrict__ Gpart, int nwb, int k,
-                                                S* __restrict__ red, const DevState* __restrict__ st) {
+__global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ Zpart, i64 ldz, int nrb,
+                                                 const double* __restrict__ Gpart, int nwb, int k,
+                                                 double* __restrict__ red, const DevState* __restrict__ st) {
     if (st->halt) return;
+    __shared__ double sh[32 * 33];
     const int tid = threadIdx.x;
     if (blockIdx.x + 1 < gridDim.x) {
-        const i64 j = (i64)blockIdx.x * 256 + tid;
-        if (j < ldz) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int b = 0;
-            for (; b + 4 <= nrb; b += 4) {
-                a0 += (double)Zpart[(i64)(b + 0) * ldz + j];
-                a1 += (double)Zpart[(i64)(b + 1) * ldz + j];
-                a2 += (double)Zpart[(i64)(b + 2) * ldz + j];
-                a3 += (double)Zpart[(i64)(b + 3) * ldz + j];
-            }
-            for (; b < nrb; ++b) a0 += (double)Zpart[(i64)b * ldz + j];
-            red[j] = (S)((a0 + a1) + (a2 + a3));
+        const int c = tid & 31, g = tid >> 5;
+        const i64 j = (i64)blockIdx.x * 32 + c;
+        double a = 0.0;
+        if (j < ldz)
+            for (int b = g; b < nrb; b += 32) a += Zpart[(i64)b * ldz + j];
+        sh[g * 33 + c] = a;
+        __syncthreads();
+        if (tid < 32 && j < ldz) {   // here c == tid
+            double s = 0.0;
+            for (int q = 0; q < 32; ++q) s += sh[q * 33 + tid];
+            red[j] = s;
         }
     } else {
-        for (int l = tid; l < k + 2; l += 256) {
+        const int lane = tid & 63, wave = tid >> 6;  // 16 waves
+        for (int l0 = 0; l0 < k + 2; l0 += 64) {
+            const int l = l0 + lane;
             double a = 0.0;
-            for (int b = 0; b < nwb; ++b) a += Gpart[(i64)b * (k + 2) + l];
-            red[ldz + l] = (S)a;
+            if (l < k + 2)
+                for (int b = wave; b < nwb; b += 16) a += Gpart[(i64)b * (k + 2) + l];
+            __syncthreads();
+            sh[wave * 64 + lane] = a;
+            __syncthreads();
+            if (wave == 0 && l < k + 2) {
+                double s = 0.0;
+                for (int q = 0; q < 16; ++q) s += sh[q * 64 + lane];
+                red[ldz + l] = s;
+            }
         }
     }
 }
@@ -330,21 +336,21 @@ __global__ __launch_bounds__(256) void k_reduce(const S* __restrict__ Zpart, i64
 // =========================================================================================
 // k_trow_numer: numerator of the T-row update and the closed-form minimiser (before any
 // simplex projection).  Also evaluates the pending W-column check of the previous topic
-// (_check_reset_W + assert, nmf.py:471-476) from the reduced column sum.
+// (_check_reset_W + assert, nmf.py:471-476) from the reduced column sum.  When no projection
+// follows, the new row is written straight into T.  blockDim = 128.
 // =========================================================================================
-template <typename S>
-__global__ __launch_bounds__(256) void k_trow_numer(const S* __restrict__ T, i64 ldt, int d, int k, int t,
-                                                    const S* __restrict__ red, i64 ldz, S* __restrict__ xraw,
-                                                    double* __restrict__ tpart, i64* __restrict__ tpart_idx,
-                                                    int check_prev, int tprev, int sweep, KParams p,
-                                                    DevState* st) {
+__global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 ldt, int d, int k, int t,
+                                                    const double* __restrict__ red, i64 ldz,
+                                                    double* __restrict__ xraw, double* __restrict__ tpart,
+                                                    i64* __restrict__ tpart_idx, int check_prev, int tprev,
+                                                    int sweep, KParams p, DevState* st) {
     if (st->halt) return;
     const int tid = threadIdx.x;
     __shared__ double scratch[40];
-    __shared__ S gsh[512];
-    const double nw = (double)red[ldz + k];
+    __shared__ double gsh[256];
+    const double nw = red[ldz + k];
     if (check_prev) {
-        const double sw = (double)red[ldz + k + 1];
+        const double sw = red[ldz + k + 1];
         const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
         const bool err = !ev && !(sw > 0.0);
         if (ev || err) {
@@ -372,33 +378,41 @@ __global__ __launch_bounds__(256) void k_trow_numer(const S* __restrict__ T, i64
             return;
         }
     }
-    for (int l = tid; l < k; l += 256) gsh[l] = (l == t) ? S(0) : red[ldz + l];
+    for (int l = tid; l < k; l += 128) gsh[l] = (l == t) ? 0.0 : red[ldz + l];
     __syncthreads();
-    const i64 j = (i64)blockIdx.x * 256 + tid;
-    S x = S(0);
-    double mx = -1.0e300;
+    const i64 j = (i64)blockIdx.x * 128 + tid;
+    double x = 0.0, mx = -1.0e300;
     if (j < d) {
-        S acc = S(0);
-        for (int l = 0; l < k; ++l) acc = fma(gsh[l], T[(i64)l * ldt + j], acc);
-        const S numer = (red[j] - acc) - (S)p.reg_t_l1;
-        if (mode == 0) x = fmax(numer, S(0)) / ((S)c + (S)p.eps);
-        else if (mode == 1) x = ((double)(-numer) + c < 0.0) ? (S)p.t_row_sum : S(0);
-        else { x = numer; mx = (double)numer; }
+        // gsh[t] == 0, so row t may be read like the others: 4 independent chains keep loads in flight
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int l = 0;
+        for (; l + 4 <= k; l += 4) {
+            a0 = fma(gsh[l + 0], T[(i64)(l + 0) * ldt + j], a0);
+            a1 = fma(gsh[l + 1], T[(i64)(l + 1) * ldt + j], a1);
+            a2 = fma(gsh[l + 2], T[(i64)(l + 2) * ldt + j], a2);
+            a3 = fma(gsh[l + 3], T[(i64)(l + 3) * ldt + j], a3);
+        }
+        for (; l < k; ++l) a0 = fma(gsh[l], T[(i64)l * ldt + j], a0);
+        const double acc = (a0 + a1) + (a2 + a3);
+        const double numer = (red[j] - acc) - p.reg_t_l1;
+        if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
+        else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
+        else { x = numer; mx = numer; }
         xraw[j] = x;
+        if (mode == 1 || (mode == 0 && !project)) T[(i64)t * ldt + j] = x;
     }
     if (mode != 2) {
-        const double s = block_sum((double)x, scratch);
+        const double s = block_sum(x, scratch);
         if (tid == 0) tpart[blockIdx.x] = s;
     } else {
         i64 idx = (j < d) ? j : (i64)0x7fffffffffffffffLL;
         wave_argmax(mx, idx);
-        __shared__ double wm[4];
-        __shared__ i64 wi[4];
+        __shared__ double wm[2];
+        __shared__ i64 wi[2];
         if ((tid & 63) == 0) { wm[tid >> 6] = mx; wi[tid >> 6] = idx; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (wm[w] > wm[0] || (wm[w] == wm[0] && wi[w] < wi[0])) { wm[0] = wm[w]; wi[0] = wi[w]; }
+            if (wm[1] > wm[0] || (wm[1] == wm[0] && wi[1] < wi[0])) { wm[0] = wm[1]; wi[0] = wi[1]; }
             tpart[blockIdx.x] = wm[0];
             tpart_idx[blockIdx.x] = wi[0];
         }
@@ -408,15 +422,14 @@ __global__ __launch_bounds__(256) void k_trow_numer(const S* __restrict__ T, i64
 
 // Michelot's fixed point for the Euclidean simplex projection (same active set, hence the same
 // theta = (sum_active - s)/|active|, as the sort of matrixops.py:58-63).  Single workgroup.
-template <typename S>
-__device__ double simplex_theta(const S* v, int d, double s, double* scratch, int* iters) {
+__device__ inline double simplex_theta(const double* v, int d, double s, double* scratch, int* iters) {
     double theta = -1.0e300;
     i64 cnt_prev = -1;
     int it = 0;
     for (; it < d + 2; ++it) {
         double sum = 0.0, cnt = 0.0;
         for (int j = threadIdx.x; j < d; j += blockDim.x) {
-            const double x = (double)v[j];
+            const double x = v[j];
             if (x > theta) { sum += x; cnt += 1.0; }
         }
         sum = block_sum(sum, scratch);
@@ -433,10 +446,10 @@ __device__ double simplex_theta(const S* v, int d, double s, double* scratch, in
 // =========================================================================================
 // k_trow_final: finishes qf_min (simplex projection or one-hot), the row checks of
 // _project_and_check_reset_t (nmf.py:751-769) and writes T[t,:].  One workgroup of 1024.
+// `light` = no projection configured: the row is already in T and only the sums are needed.
 // =========================================================================================
-template <typename S>
-__global__ __launch_bounds__(1024) void k_trow_final(S* __restrict__ T, i64 ldt, int d, int t,
-                                                     S* __restrict__ xraw, const double* __restrict__ tpart,
+__global__ __launch_bounds__(1024) void k_trow_final(double* __restrict__ T, i64 ldt, int d, int t,
+                                                     double* __restrict__ xraw, const double* __restrict__ tpart,
                                                      const i64* __restrict__ tpart_idx, int nblk, int sweep,
                                                      KParams p, DevState* st) {
     if (st->halt) return;
@@ -444,41 +457,52 @@ __global__ __launch_bounds__(1024) void k_trow_final(S* __restrict__ T, i64 ldt,
     const int tid = threadIdx.x;
     const int mode = st->tmode;
     const bool project = p.project_T && p.has_trs;
-    double nx = 1.0;
+    double nx = 1.0, sumT = 0.0;
     int iters = 0;
+    bool row_dirty = false;  // xraw differs from what k_trow_numer stored in T
     if (mode == 2) {
         double bm = tpart[0];
         i64 bi = tpart_idx[0];
         for (int b = 1; b < nblk; ++b)
             if (tpart[b] > bm) { bm = tpart[b]; bi = tpart_idx[b]; }
-        for (int j = tid; j < d; j += blockDim.x) xraw[j] = (j == bi) ? S(1) : S(0);
-    } else if (mode == 0) {
-        nx = 0.0;
-        for (int b = 0; b < nblk; ++b) nx += tpart[b];
-        if (project) {
-            const double th = simplex_theta<S>(xraw, d, p.t_row_sum, scratch, &iters);
-            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - (S)th, S(0));
+        for (int j = tid; j < d; j += blockDim.x) xraw[j] = (j == bi) ? 1.0 : 0.0;
+        row_dirty = true;
+    } else {
+        double ps = 0.0;
+        for (int b = tid; b < nblk; b += blockDim.x) ps += tpart[b];
+        ps = block_sum(ps, scratch);
+        if (mode == 0) nx = ps;
+        sumT = ps;
+        if (mode == 0 && project) {
+            const double th = simplex_theta(xraw, d, p.t_row_sum, scratch, &iters);
+            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - th, 0.0);
             if (tid == 0) st->theta = th;
+            row_dirty = true;
         }
     }
-    __syncthreads();
-    double sumT = 0.0;
-    for (int j = tid; j < d; j += blockDim.x) sumT += (double)xraw[j];
-    sumT = block_sum(sumT, scratch);
+    if (row_dirty) {
+        __syncthreads();
+        sumT = 0.0;
+        for (int j = tid; j < d; j += blockDim.x) sumT += xraw[j];
+        sumT = block_sum(sumT, scratch);
+    }
     bool event = false;
     if (sumT > 1e-10 || p.reset_method == RESET_NONE) {
         // nmf.py:759-761: project again when the row is not on the simplex to 1e-15
         if (p.has_trs && p.t_row_sum != 0.0 && p.project_T && fabs(sumT - p.t_row_sum) > 1e-15) {
             int it2 = 0;
-            const double th = simplex_theta<S>(xraw, d, p.t_row_sum, scratch, &it2);
-            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - (S)th, S(0));
+            const double th = simplex_theta(xraw, d, p.t_row_sum, scratch, &it2);
+            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - th, 0.0);
             iters += it2;
+            row_dirty = true;
         }
     } else if (p.resets_left > 0) {
         event = true;
     }
-    __syncthreads();
-    for (int j = tid; j < d; j += blockDim.x) T[(i64)t * ldt + j] = xraw[j];
+    if (row_dirty) {
+        __syncthreads();
+        for (int j = tid; j < d; j += blockDim.x) T[(i64)t * ldt + j] = xraw[j];
+    }
     if (tid == 0) {
         st->nt1 = nx;
         st->sumT = sumT;
@@ -487,47 +511,35 @@ __global__ __launch_bounds__(1024) void k_trow_final(S* __restrict__ T, i64 ldt,
     }
 }
 
-// k_tgram: Tt[l] = <T[l,:], T[t,:]> (entry t zeroed, nmf.py:730-732); nt = ||T[t,:]||^2 (:734).
-template <typename S>
-__global__ __launch_bounds__(256) void k_tgram(const S* __restrict__ T, i64 ldt, int d, int t,
-                                               S* __restrict__ Tt, DevState* st) {
+// k_tgram: partial T T[t,:]^T over column slice blockIdx.y: Ttpart[y][l] = <T[l,slice], T[t,slice]>
+// (entry l == t is the slice's share of ||T[t,:]||^2; k_wcol sums the slices, nmf.py:730-734).
+__global__ __launch_bounds__(256) void k_tgram(const double* __restrict__ T, i64 ldt, int d, int k, int t,
+                                               double* __restrict__ Ttpart, const DevState* __restrict__ st) {
     if (st->halt) return;
     __shared__ double scratch[40];
     const int l = blockIdx.x;
+    const int ns = gridDim.y;
+    const int chunk = (d + ns - 1) / ns;
+    const int j0 = blockIdx.y * chunk, j1 = min(d, j0 + chunk);
     double acc = 0.0;
-    for (int j = threadIdx.x; j < d; j += 256)
-        acc += (double)T[(i64)l * ldt + j] * (double)T[(i64)t * ldt + j];
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) acc = fma(T[(i64)l * ldt + j], T[(i64)t * ldt + j], acc);
     acc = block_sum(acc, scratch);
-    if (threadIdx.x == 0) {
-        if (l == t) { st->nt = acc; Tt[l] = S(0); }
-        else Tt[l] = (S)acc;
-    }
+    if (threadIdx.x == 0) Ttpart[blockIdx.y * k + l] = acc;
 }
 
 // W[:,t] *= nt1 (nmf.py:450-452); only observable when fix_W keeps the column.
-template <typename S>
-__global__ __launch_bounds__(256) void k_scale_wcol(S* W, int n, int k, int t, const DevState* st) {
+__global__ __launch_bounds__(256) void k_scale_wcol(double* Wt, i64 ldw, int n, int t, const DevState* st) {
     if (st->halt) return;
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) W[i * k + t] = W[i * k + t] * (S)st->nt1;
-}
-
-// wcol[i] = W[i, col]: contiguous copy of the active column for the streaming pass
-template <typename S>
-__global__ __launch_bounds__(256) void k_extract_col(const S* __restrict__ W, int n, int k, int col,
-                                                     S* __restrict__ wcol, const DevState* __restrict__ st) {
-    if (st->halt) return;
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) wcol[i] = W[i * k + col];
+    if (i < n) Wt[(i64)t * ldw + i] *= st->nt1;
 }
 
 // the W-column check alone, against the reduced buffer (row-sharded runs, after the last sweep)
-template <typename S>
-__global__ __launch_bounds__(64) void k_check_red(const S* __restrict__ red, i64 ldz, int k, int tprev, int sweep, int pos, KParams p,
-                            DevState* st) {
+__global__ __launch_bounds__(64) void k_check_red(const double* __restrict__ red, i64 ldz, int k, int tprev,
+                                                  int sweep, int pos, KParams p, DevState* st) {
     if (st->halt) return;
     if (threadIdx.x == 0) {
-        const double sw = (double)red[ldz + k + 1];
+        const double sw = red[ldz + k + 1];
         const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
         const bool err = !ev && !(sw > 0.0);
         if (ev || err) {
@@ -538,9 +550,8 @@ __global__ __launch_bounds__(64) void k_check_red(const S* __restrict__ red, i64
 }
 
 // stand-alone W-column check for the paths without a following T-row step
-template <typename S>
-__global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ Gpart, int nwb, int k, int tprev, int sweep, int pos,
-                             KParams p, DevState* st) {
+__global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ Gpart, int nwb, int k, int tprev,
+                                                    int sweep, int pos, KParams p, DevState* st) {
     if (st->halt) return;
     __shared__ double scratch[40];
     double a = 0.0;
@@ -558,43 +569,28 @@ __global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ G
 
 // =========================================================================================
 // k_proj_rows: Euclidean projection of every row of W on the simplex of radius s (scalar) or
-// s_vec[i] (matrixops.py:72-100; nmf.py:481-484, 519-529).  One thread per row, tile in LDS.
+// s_vec[i] (matrixops.py:72-100; nmf.py:481-484, 519-529).  One thread per row; the k entries
+// of a row are k coalesced loads from the k-major Wt (re-read per Michelot iteration from L2).
 // =========================================================================================
-template <typename S>
-__global__ __launch_bounds__(256) void k_proj_rows(S* __restrict__ W, int n, int k, double s_scalar, const double* __restrict__ s_vec) {
-    const int RW = blockDim.x, tid = threadIdx.x, kp = k + 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    S* wt = reinterpret_cast<S*>(smem);
-    const i64 row0 = (i64)blockIdx.x * RW;
-    const int rows_here = (int)min((i64)RW, (i64)n - row0);
-    for (int idx = tid; idx < rows_here * k; idx += RW) {
-        const int r = idx / k, l = idx - r * k;
-        wt[r * kp + l] = W[row0 * k + idx];
-    }
-    __syncthreads();
-    if (tid < rows_here) {
-        const double s = s_vec ? s_vec[row0 + tid] : s_scalar;
-        S* v = wt + tid * kp;
-        double theta = -1.0e300;
-        int cnt_prev = -1;
-        for (int it = 0; it < k + 2; ++it) {
-            double sum = 0.0;
-            int cnt = 0;
-            for (int l = 0; l < k; ++l) {
-                const double x = (double)v[l];
-                if (x > theta) { sum += x; ++cnt; }
-            }
-            if (cnt == cnt_prev || cnt == 0) break;
-            theta = (sum - s) / (double)cnt;
-            cnt_prev = cnt;
+__global__ __launch_bounds__(256) void k_proj_rows(double* __restrict__ Wt, i64 ldw, int n, int k, double s_scalar,
+                                                   const double* __restrict__ s_vec) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double s = s_vec ? s_vec[i] : s_scalar;
+    double theta = -1.0e300;
+    int cnt_prev = -1;
+    for (int it = 0; it < k + 2; ++it) {
+        double sum = 0.0;
+        int cnt = 0;
+        for (int l = 0; l < k; ++l) {
+            const double x = Wt[(i64)l * ldw + i];
+            if (x > theta) { sum += x; ++cnt; }
         }
-        for (int l = 0; l < k; ++l) v[l] = fmax(v[l] - (S)theta, S(0));
+        if (cnt == cnt_prev || cnt == 0) break;
+        theta = (sum - s) / (double)cnt;
+        cnt_prev = cnt;
     }
-    __syncthreads();
-    for (int idx = tid; idx < rows_here * k; idx += RW) {
-        const int r = idx / k, l = idx - r * k;
-        W[row0 * k + idx] = wt[r * kp + l];
-    }
+    for (int l = 0; l < k; ++l) Wt[(i64)l * ldw + i] = fmax(Wt[(i64)l * ldw + i] - theta, 0.0);
 }
 
 // =========================================================================================
@@ -607,8 +603,8 @@ __global__ __launch_bounds__(256) void k_proj_rows(S* __restrict__ W, int n, int
 // =========================================================================================
 template <typename SX, bool MASKED, bool WRITE_E>
 __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M, i64 ldm,
-                                               const double* __restrict__ W, const double* __restrict__ T, i64 ldt,
-                                               int n, int d, int k, double* __restrict__ rowobj,
+                                               const double* __restrict__ Wt, i64 ldw, const double* __restrict__ T,
+                                               i64 ldt, int n, int d, int k, double* __restrict__ rowobj,
                                                double* __restrict__ rowpos, SX* __restrict__ E, i64 lde) {
     typedef double S;
     constexpr int KC = 32;
@@ -619,8 +615,8 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const i64 row0 = (i64)blockIdx.x * 64;
     for (int idx = tid; idx < 64 * k; idx += 256) {
-        const int r = idx / k, l = idx - r * k;
-        Wsh[l * 64 + r] = (row0 + r < n) ? W[(row0 + r) * k + l] : S(0);
+        const int l = idx >> 6, r = idx & 63;
+        Wsh[l * 64 + r] = (row0 + r < n) ? Wt[(i64)l * ldw + row0 + r] : S(0);
     }
     double so[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
     for (i64 c0 = 0; c0 < d; c0 += 64) {
@@ -683,15 +679,14 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
 }
 
 // partial sums of v, v^2 and |v| over a strided matrix: out[b] = {sum, sumsq, sumabs}
-template <typename S>
-__global__ __launch_bounds__(256) void k_norms(const S* __restrict__ A, i64 rows, i64 cols, i64 ld,
+__global__ __launch_bounds__(256) void k_norms(const double* __restrict__ A, i64 rows, i64 cols, i64 ld,
                                                double* __restrict__ out) {
     __shared__ double scratch[40];
     double s1 = 0, s2 = 0, s3 = 0;
     const i64 total = rows * cols;
     for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
         const i64 r = idx / cols, c = idx - r * cols;
-        const double v = (double)A[r * ld + c];
+        const double v = A[r * ld + c];
         s1 += v; s2 += v * v; s3 += fabs(v);
     }
     s1 = block_sum(s1, scratch);
@@ -727,64 +722,59 @@ __global__ __launch_bounds__(1024) void k_vec_sum_argmax(const double* __restric
 
 // 'max_resid_document' reset, step 1: row = max(X[mi,:] - W[mi,:] T, 0) (nmf.py:771,774)
 template <typename SX>
-__global__ __launch_bounds__(256) void k_reset_row(const SX* __restrict__ X, i64 ldx, const double* __restrict__ W,
-                                                   const double* __restrict__ T, i64 ldt, int d, int k,
+__global__ __launch_bounds__(256) void k_reset_row(const SX* __restrict__ X, i64 ldx, const double* __restrict__ Wt,
+                                                   i64 ldw, const double* __restrict__ T, i64 ldt, int d, int k,
                                                    const i64* __restrict__ mi_ptr, double* __restrict__ rowout) {
-    typedef double S;
     const i64 mi = *mi_ptr;
     const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
     if (j >= d) return;
-    S acc = S(0);
-    for (int l = 0; l < k; ++l) acc = fma(W[mi * k + l], T[(i64)l * ldt + j], acc);
-    rowout[j] = fmax((S)X[mi * ldx + j] - acc, S(0));
+    double acc = 0.0;
+    for (int l = 0; l < k; ++l) acc = fma(Wt[(i64)l * ldw + mi], T[(i64)l * ldt + j], acc);
+    rowout[j] = fmax((double)X[mi * ldx + j] - acc, 0.0);
 }
 // step 2: T[t,:] = row ; W[:,t] = e_mi (nmf.py:774-776)
-template <typename S>
-__global__ __launch_bounds__(256) void k_reset_commit(S* __restrict__ W, S* __restrict__ T, i64 ldt, int n, int d,
-                                                      int k, int t, const i64* __restrict__ mi_ptr,
-                                                      const S* __restrict__ rowin) {
+__global__ __launch_bounds__(256) void k_reset_commit(double* __restrict__ Wt, i64 ldw, double* __restrict__ T,
+                                                      i64 ldt, int n, int d, int t, const i64* __restrict__ mi_ptr,
+                                                      const double* __restrict__ rowin) {
     const i64 mi = *mi_ptr;
     const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
     if (idx < d) T[(i64)t * ldt + idx] = rowin[idx];
-    if (idx < n) W[idx * k + t] = (idx == mi) ? S(1) : S(0);
+    if (idx < n) Wt[(i64)t * ldw + idx] = (idx == mi) ? 1.0 : 0.0;
 }
 // explicit reset vectors ('random', nmf.py:778-783): T[t,:] and W[:,t] from double buffers
-template <typename S>
-__global__ __launch_bounds__(256) void k_set_row_col(S* __restrict__ W, S* __restrict__ T, i64 ldt, int n, int d,
-                                                     int k, int t, const double* __restrict__ trow,
+__global__ __launch_bounds__(256) void k_set_row_col(double* __restrict__ Wt, i64 ldw, double* __restrict__ T,
+                                                     i64 ldt, int n, int d, int t, const double* __restrict__ trow,
                                                      const double* __restrict__ wcolv) {
     const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (trow && idx < d) T[(i64)t * ldt + idx] = (S)trow[idx];
-    if (wcolv && idx < n) W[idx * k + t] = (S)wcolv[idx];
+    if (trow && idx < d) T[(i64)t * ldt + idx] = trow[idx];
+    if (wcolv && idx < n) Wt[(i64)t * ldw + idx] = wcolv[idx];
 }
 
-template <typename S>
-__global__ __launch_bounds__(256) void k_argmax_rows(const S* __restrict__ W, int n, int k, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_argmax_rows(const double* __restrict__ Wt, i64 ldw, int n, int k,
+                                                     int* __restrict__ out) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    S best = W[i * k];
+    double best = Wt[i];
     int bi = 0;
     for (int l = 1; l < k; ++l) {
-        const S v = W[i * k + l];
+        const double v = Wt[(i64)l * ldw + i];
         if (v > best) { best = v; bi = l; }
     }
     out[i] = bi;
 }
 
 // sum over listed entries of (clip((W T)_ij) - val)^2  (sklearn_interface.py:85-91,172-182)
-template <typename S>
-__global__ __launch_bounds__(256) void k_masked_sqerr(const S* __restrict__ W, const S* __restrict__ T, i64 ldt,
-                                                      int k, const i64* __restrict__ ij,
-                                                      const double* __restrict__ vals, i64 count, double lo,
-                                                      double hi, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_masked_sqerr(const double* __restrict__ Wt, i64 ldw,
+                                                      const double* __restrict__ T, i64 ldt, int k,
+                                                      const i64* __restrict__ ij, const double* __restrict__ vals,
+                                                      i64 count, double lo, double hi, double* __restrict__ out) {
     __shared__ double scratch[40];
     double s = 0.0;
     for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < count; e += (i64)gridDim.x * 256) {
         const i64 i = ij[2 * e], j = ij[2 * e + 1];
-        S acc = S(0);
-        for (int l = 0; l < k; ++l) acc = fma(W[i * k + l], T[(i64)l * ldt + j], acc);
-        double pr = (double)acc;
-        pr = pr < lo ? lo : (pr > hi ? hi : pr);
+        double acc = 0.0;
+        for (int l = 0; l < k; ++l) acc = fma(Wt[(i64)l * ldw + i], T[(i64)l * ldt + j], acc);
+        double pr = acc < lo ? lo : (acc > hi ? hi : acc);
         const double df = pr - vals[e];
         s += df * df;
     }
@@ -792,14 +782,19 @@ __global__ __launch_bounds__(256) void k_masked_sqerr(const S* __restrict__ W, c
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
-// 2-D copy with type conversion (host staging -> padded device layout)
-template <typename Src, typename Dst>
+// 2-D copy with type conversion (host staging -> padded device layout); TRANSPOSE: dst[c][r] = src[r][c]
+template <typename Src, typename Dst, bool TRANSPOSE>
 __global__ __launch_bounds__(256) void k_convert2d(const Src* __restrict__ src, i64 lds_, Dst* __restrict__ dst,
                                                    i64 ldd, i64 rows, i64 cols) {
     const i64 total = rows * cols;
     for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-        const i64 r = idx / cols, c = idx - r * cols;
-        dst[r * ldd + c] = (Dst)src[r * lds_ + c];
+        if (TRANSPOSE) {   // idx runs along the DESTINATION rows (coalesced writes)
+            const i64 c = idx / rows, r = idx - c * rows;
+            dst[c * ldd + r] = (Dst)src[r * lds_ + c];
+        } else {
+            const i64 r = idx / cols, c = idx - r * cols;
+            dst[r * ldd + c] = (Dst)src[r * lds_ + c];
+        }
     }
 }
 

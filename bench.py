@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- RRI sweeps/sec and achieved HBM GB/s of the MI355X path (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4]
+
+A step is one RRI sweep (k topic steps = k T-row + k W-column updates, nmf.py:415-476) over a
+synthetic dense fp32 X that is already resident in HBM when the timed region starts.
+
+Workloads (BASELINE.json configs):
+    c3 (default)  100000 x 10000, k=50: the roofline run the north_star target is quoted on.
+                  N > 1: WEAK scaling -- every rank holds its own 100000-row shard of an
+                  (N*100000) x 10000 problem (T replicated, one RCCL all-reduce of (d+k+2) doubles per
+                  topic step).  `value` is the whole job's rate in sweeps/s of a 100000-row shard,
+                  i.e. N * (global sweeps/s): it equals plain sweeps/s at N = 1.
+    c2            10000 x 1000, k=20 (X is Infinity-Cache resident: latency-, not HBM-bound).
+    c4            1000000 x 10000, k=50 split by rows over the N ranks (STRONG scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task description) including
+    roofline     : the dominant kernel (the fused X pass) -- algorithmic bytes n_local*d*4 per launch
+                   over its average duration, measured with HIP events on the kernel's stream
+                   inside the timed region, against 8 TB/s
+    cpu_baseline : the float64 numpy restatement (oracle/) timed on this box's host cores on a
+                   bounded row sample of the same X, scaled linearly in n to the full workload.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    'c2': dict(n=10000, d=1000, k=20, scaling='weak', name='synthetic dense fp32 X 10000x1000 k=20'),
+    'c3': dict(n=100000, d=10000, k=50, scaling='weak', name='synthetic dense fp32 X 100000x10000 k=50'),
+    'c4': dict(n=1000000, d=10000, k=50, scaling='strong', name='synthetic dense fp32 X 1000000x10000 k=50'),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--cpu-rows', type=int, default=10000, help='rows of X in the CPU baseline sample')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child job.  Done before
+    anything touches the GPU; the child is waited for, never exec'ed over this process."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 2000),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def device_planted_shard(n_rows, d, k, seed, device):
+    """X = W* T* + 0.01 U with 30 %-dense uniform factors, generated on the device in row
+    chunks (T* is common to all shards, W* and the noise are per shard)."""
+    import torch
+    gt = torch.Generator(device=device)
+    gt.manual_seed(0)
+    Ts = torch.rand(k, d, device=device, generator=gt) * (torch.rand(k, d, device=device, generator=gt) < 0.3)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    X = torch.empty(n_rows, d, device=device, dtype=torch.float32)
+    step = 25000
+    for lo in range(0, n_rows, step):
+        hi = min(n_rows, lo + step)
+        Ws = torch.rand(hi - lo, k, device=device, generator=g) * (torch.rand(hi - lo, k, device=device, generator=g) < 0.3)
+        torch.matmul(Ws, Ts, out=X[lo:hi])
+        X[lo:hi].add_(torch.rand(hi - lo, d, device=device, generator=g), alpha=0.01)
+    return X
+
+
+def cpu_baseline(Xs_host, W0s, T0, n_full, sweeps=2):
+    """the numpy float64 restatement on the host cores: 1 warm-up + `sweeps` timed sweeps on the sample"""
+    import numpy as np
+    from oracle import rri_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    X = Xs_host.astype(np.float64)
+    W, T = W0s.astype(np.float64).copy(), T0.astype(np.float64).copy()
+    orc.plain_sweeps(X, W, T, 1)
+    t0 = time.perf_counter()
+    orc.plain_sweeps(X, W, T, sweeps)
+    dt = time.perf_counter() - t0
+    rate_sample = sweeps / dt
+    frac = X.shape[0] / float(n_full)
+    return dict(value=rate_sample * frac, unit='sweeps/s', cores=int(threads), kind='port',
+                sample='first %d of %d rows of the same X, %d timed sweeps after 1 warm-up, numpy float64 + '
+                       'OpenBLAS on %d threads (%d host cpus); sample rate %.3f sweeps/s scaled by %.4g '
+                       '(work is linear in n)' % (X.shape[0], n_full, sweeps, threads, os.cpu_count() or 0,
+                                                  rate_sample, frac)), W, T
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world == 1:
+        sys.exit(relaunch_under_torchrun(args))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard, shard_rows
+
+    cfg = CONFIGS[args.config]
+    d, k = cfg['d'], cfg['k']
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    if cfg['scaling'] == 'weak':
+        n_local, n_global = cfg['n'], cfg['n'] * world
+    else:
+        lo, hi = shard_rows(cfg['n'], world, rank)
+        n_local, n_global = hi - lo, cfg['n']
+
+    X = device_planted_shard(n_local, d, k, seed=(0 if world == 1 else 1000 + rank), device=device)
+    mean = X.sum(dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(mean)
+    mean = float(mean) / (float(n_global) * d)
+    a = (mean / k) ** 0.5
+    gi = torch.Generator(device=device)
+    gi.manual_seed(1)
+    T0 = (a * torch.rand(k, d, device=device, generator=gi, dtype=torch.float64)).cpu().numpy()   # same on all ranks
+    gw = torch.Generator(device=device)
+    gw.manual_seed(2000 + rank)
+    W0 = (a * torch.rand(n_local, k, device=device, generator=gw, dtype=torch.float64)).cpu().numpy()
+    torch.cuda.synchronize()
+
+    eng, red, stream = make_device_shard(n_local, d, k, dtype=np.float32, device_index=local_rank)
+    eng.bind_X_device(X.data_ptr(), X.stride(0))
+    eng.set_W(W0)
+    eng.set_T(T0)
+    eng.set_params()     # plain RRI: no constraints, default reset policy
+    drv = ShardedRRI(eng, red, k, stream=stream) if world > 1 else None
+
+    def run(steps):
+        if drv is None:
+            eng.sweep(steps)
+        else:
+            drv.sweep(steps)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    fence()
+    eng.timing_enable(True)
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.timing_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    launches, pass_ms = eng.timing_read(0)
+    _, wcol_ms = eng.timing_read(1)
+    _, trow_ms = eng.timing_read(2)
+    pass_avg_ms = pass_ms / max(launches, 1)
+    bytes_per_launch = float(n_local) * d * 4
+    achieved = bytes_per_launch / (pass_avg_ms * 1e-3) / 1e9 if launches else 0.0
+    sweeps_per_s = args.steps / elapsed
+    shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
+    value = sweeps_per_s * shards
+
+    out = {
+        'metric': 'RRI sweeps/sec and achieved HBM GB/s on dense X (n x d, rank k)',
+        'value': value, 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': cfg['scaling'],
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': cfg['name'] + (' per GPU (row shard), %d x %d global' % (n_global, d)
+                                              if world > 1 and cfg['scaling'] == 'weak' else ''),
+                   'n_global': n_global, 'n_per_gpu': n_local, 'd': d, 'k': k,
+                   'x_storage': 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'plain RRI',
+                   'parallelism': 'row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step'
+                                  % (world, d + k + 2) if world > 1 else 'single GPU'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                     'kernel': 'k_pass<float,Y,Z> (fused row-dot + column-sum pass over X)',
+                     'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},
+        'sweep_level': {'global_sweeps_per_s': sweeps_per_s,
+                        'x_passes_per_sweep': launches / float(args.steps) if args.steps else None,
+                        'algorithmic_GBps_2knd': 2.0 * k * n_local * d * 4 * sweeps_per_s / 1e9,
+                        'frac_of_8TBps_2knd': 2.0 * k * n_local * d * 4 * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
+                        'kernel_ms_per_sweep': {'pass': pass_ms / args.steps, 'wcol': wcol_ms / args.steps,
+                                                'trow_chain': trow_ms / args.steps}},
+    }
+
+    if rank == 0 and world == 1:
+        # the explicit rank-one residual update R <- R - a b^T (read + write, fused residual products)
+        try:
+            r1_ms = eng.bench_rank1_update(5)
+            cp_ms = eng.bench_stream_copy(5)
+            out['rank1_update'] = {'bound': 'hbm', 'achieved': 2 * bytes_per_launch / (r1_ms * 1e-3) / 1e9,
+                                   'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                   'frac': 2 * bytes_per_launch / (r1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   'bytes_per_launch': 2 * bytes_per_launch, 'avg_ms': r1_ms,
+                                   'stream_copy_GBps': 2 * bytes_per_launch / (cp_ms * 1e-3) / 1e9}
+        except Exception as e:  # noqa: BLE001
+            out['rank1_update'] = {'error': str(e)}
+        if not args.no_cpu_baseline:
+            rows = min(args.cpu_rows, n_local)
+            Xs = X[:rows].cpu().numpy()
+            cb, Wc, Tc = cpu_baseline(Xs, W0[:rows], T0, n_local)
+            out['cpu_baseline'] = cb
+            # parity in the same run: the device path on the same sample, equal sweeps (1 + 2)
+            from rri_nmf_amd.engine import RRIEngine
+            with RRIEngine(rows, d, k, dtype=np.float32, device=local_rank) as e2:
+                e2.upload_X(Xs)
+                e2.set_W(W0[:rows])
+                e2.set_T(T0)
+                e2.set_params()
+                e2.sweep(3)
+                Wg, Tg = e2.get_W(), e2.get_T()
+            out['parity_sample'] = {
+                'sweeps': 3, 'rows': rows,
+                'relfro_W': float(np.linalg.norm(Wg - Wc) / np.linalg.norm(Wc)),
+                'relfro_T': float(np.linalg.norm(Tg - Tc) / np.linalg.norm(Tc)),
+                'relfro_WT': float(np.linalg.norm(Wg @ Tg - Wc @ Tc) / np.linalg.norm(Wc @ Tc))}
+            out['gpu_over_cpu'] = value / cb['value'] if cb['value'] else None
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

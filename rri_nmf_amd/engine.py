@@ -221,6 +221,11 @@ class RRIEngine(object):
         self._check(self._lib.rri_objective_parts(self._h, out))
         return [float(v) for v in out]
 
+    def t_norms(self):
+        """(sum T^2, sum |T|) of the replicated T, for the sharded objective"""
+        T = self.get_T()
+        return float((T ** 2).sum()), float(np.abs(T).sum())
+
     def argmax_rows(self):
         out = np.empty(self.n, dtype=np.int32)
         self._check(self._lib.rri_argmax_rows(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))

@@ -1,0 +1,286 @@
+"""nmf(): drop-in for the reference's solver entry point (/root/reference/src/rri_nmf/nmf.py:98-560)
+with the sweep / topic loop running on an MI355X through librri_hip.so.
+
+Same signature, defaults, return keys and error behaviour as the reference; two keyword-only
+additions select the device side:
+    dtype   storage type of X (and the mask) in HBM: float32 or float64.  None = float32 when X is
+            float32, else float64.  The arithmetic is float64 either way (see csrc/rri_kernels.hpp).
+    device  HIP device ordinal.
+
+What runs where
+    host (numpy, once):   argument checks, warnings and sentinel returns (nmf.py:280-315), the
+                          starting point (nmf.py:819-880), the stop rules, callbacks
+    device (every sweep): residual products, closed-form updates, projections, resets, objective
+There is no CPU fallback for the loop: without the library / a GPU the call raises.
+"""
+import logging
+import time
+
+import numpy as np
+import scipy.sparse
+
+from .engine import RRIEngine
+from .initialization import initialize_nmf
+from .matrixops import normalize, proj_mat_to_simplex
+from .optimization import universal_stopping_condition
+
+# The reference configures logging the same way (nmf.py:46-47).  A module logger created like this has
+# level NOTSET (0), so `logger.level <= logging.DEBUG` below is true unless the caller sets a level --
+# in the reference (nmf.py:366) and therefore here: the objective is then evaluated every sweep and the
+# obj-history stop rule is active.  Call `logger.setLevel(logging.WARNING)` for the documented behaviour.
+logging.basicConfig(level=logging.WARNING)
+logger = logging.getLogger(__name__)
+
+eps_div_by_zero = np.spacing(10)  # nmf.py:52
+
+
+class TrueObjComputer(object):
+    """Handle returned as rtv['obj_calculator'] (nmf.py:58-94): remembers the problem and the last
+    objective value; true_objective() re-evaluates it on the device."""
+
+    def __init__(self, X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, Wm, wr, dtype=None, device=0):
+        self.X, self.W, self.T = X, W, T
+        self.reg_w_l2, self.reg_t_l2 = reg_w_l2, reg_t_l2
+        self.reg_w_l1, self.reg_t_l1 = reg_w_l1, reg_t_l1
+        self.Wm, self.wr = Wm, wr
+        self.obj = np.inf
+        self._dtype, self._device = dtype, device
+
+    def true_objective(self):
+        X = self.X if self.wr is None else self.X  # w_row is already folded into X by nmf()
+        n, d = X.shape
+        k = self.W.shape[1]
+        with RRIEngine(n, d, k, dtype=_storage_dtype(X, self._dtype), weighted=self.Wm is not None,
+                       device=self._device) as eng:
+            eng.upload_X(X)
+            if self.Wm is not None:
+                eng.upload_mask(self.Wm)
+            eng.set_W(self.W)
+            eng.set_T(self.T)
+            eng.set_params(reg_w_l1=self.reg_w_l1, reg_w_l2=self.reg_w_l2, reg_t_l1=self.reg_t_l1,
+                           reg_t_l2=self.reg_t_l2)
+            self.obj = eng.objective()
+        return self.obj
+
+
+def _storage_dtype(X, dtype):
+    if dtype is not None:
+        return np.dtype(dtype)
+    return np.dtype(np.float32) if getattr(X, 'dtype', None) == np.float32 else np.dtype(np.float64)
+
+
+def _is_empty(a):
+    return int(np.prod(np.shape(a))) == 0
+
+
+def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, project_T_each_iter,
+                             project_W_each_iter, w_row_sum, t_row_sum, fix_W, fix_T, n, d, **_):
+    """Starting W, T (nmf.py:819-880): initialise BOTH when either input is empty, let W_in / T_in
+    override, clamp at 0 (copies: the caller's arrays are never written), project when the
+    constraints are kept every sweep."""
+    if _is_empty(W_in) or _is_empty(T_in):
+        src = X if W_mat is None else W_mat * X
+        W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False)
+        if t_row_sum is not None:
+            T = normalize(T) * t_row_sum
+        if w_row_sum is not None:
+            W = normalize(W) * w_row_sum
+    if not _is_empty(W_in):
+        if np.shape(W_in) != (n, k):
+            raise ValueError('W_in has wrong dimensions, must be n*k')
+        W = W_in
+    if not _is_empty(T_in):
+        if np.shape(T_in) != (k, d):
+            raise ValueError('T_in has wrong dimensions, must be k*d')
+        T = T_in
+    if scipy.sparse.issparse(T):
+        T = T.toarray()
+    if scipy.sparse.issparse(W):
+        W = W.toarray()
+    W = np.maximum(W, 0)
+    T = np.maximum(T, 0)
+    if project_W_each_iter and not fix_W and w_row_sum is not None:
+        W = proj_mat_to_simplex(W, w_row_sum)
+    if project_T_each_iter and not fix_T and t_row_sum is not None:
+        T = proj_mat_to_simplex(T, t_row_sum)
+    return W, T
+
+
+def _sentinel(W, T):
+    return {'W': W, 'T': T, 'obj_history': [-np.inf], 'iter_cputime': [0]}
+
+
+def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
+        random_state=None, init='nndsvd', T_in=[], W_in=[], max_iter=200,
+        max_time=600, eps_stop=1e-4, compute_obj_each_iter=False,
+        project_W_each_iter=False, w_row_sum=None,
+        do_final_project_W=True, project_T_each_iter=False,
+        t_row_sum=None, early_stop=None,
+        reset_topic_method='max_resid_document', fix_reset_seed=False,
+        n_resets=23,
+        reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0,
+        diagnostics=[], store_gradients=False,
+        ind_rows_to_store=None, eps_gauss_t=None, delta_gauss_t=None,
+        *, dtype=None, device=0):
+    """Non-negative factorisation X ~ W T by rank-one residue iteration; see the module docstring and
+    the reference's docstring (nmf.py:109-269) for the parameters.  Returns a dict with 'W', 'T',
+    'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
+    is tracked, 'obj_history' and 'obj_calculator'; 'diagnostics' when callbacks are given."""
+    if store_gradients or ind_rows_to_store is not None:
+        raise NotImplementedError('store_gradients is not available on the device path '
+                                  '(SURVEY.md section 8f rank 4)')
+    if eps_gauss_t or delta_gauss_t:
+        raise NotImplementedError('the Gaussian mechanism (eps_gauss_t/delta_gauss_t) is not available '
+                                  'on the device path (SURVEY.md section 8f rank 4)')
+    if scipy.sparse.issparse(X):
+        X = X.toarray()
+    X = np.asarray(X)
+    rtv = {}
+    n, d = X.shape
+
+    # ---- option sanity, exactly as nmf.py:280-315 ---------------------------------------------
+    if project_T_each_iter and np.any([reg_w_l1, reg_t_l1]):
+        logger.warning('This implementation can not solve project_T_each_iter=True with '
+                       'regularization. Because WT is no longer scale invariant. Setting '
+                       'project_T_each_iter to False.')
+        project_T_each_iter = False
+    if project_W_each_iter and reg_w_l2 < 0:
+        logger.warning('project_W_each_iter={} and reg_w_l2={}<0 doesnt converge with the current '
+                       'implementation.'.format(project_W_each_iter, reg_w_l2))
+    if (not project_T_each_iter and not t_row_sum) and (reg_t_l1 < 0 or reg_t_l2 < 0):
+        logger.error('Unbounded objective. reg_t_l1={}, reg_t_l2={} but project_T_each_iter={} and '
+                     't_row_sum={}'.format(reg_t_l1, reg_t_l2, project_T_each_iter, t_row_sum))
+        return _sentinel(np.ones((n, k)), np.ones((k, d)) * 1e6)
+    if (not project_W_each_iter and not w_row_sum) and (reg_w_l1 < 0 or reg_w_l2 < 0):
+        logger.error('Unbounded objective. reg_w_l1={}, reg_w_l2={} but project_W_each_iter={} and '
+                     'w_row_sum={}'.format(reg_w_l1, reg_w_l2, project_W_each_iter, w_row_sum))
+        return _sentinel(np.ones((n, k)) * 1e6, np.ones((k, d)))
+
+    if type(diagnostics) is not list:
+        diagnostics = [diagnostics]
+    if diagnostics:
+        rtv['diagnostics'] = {f.__name__: [] for f in diagnostics}
+    if random_state is None:
+        random_state = int(time.time()) % 4294967296
+
+    wall0 = time.time()
+    max_time = max_time - 10  # nmf.py:333
+
+    X_orig = None
+    if w_row is not None:                       # nmf.py:335-338
+        X_orig = X.copy()
+        X = np.sqrt(w_row) * X
+    if w_row_sum is not None and not np.isscalar(w_row_sum):   # nmf.py:340-344
+        w_row_sum = w_row_sum.reshape((w_row_sum.size, 1))
+        if w_row is not None:
+            w_row_sum = np.sqrt(w_row_sum)
+    if n <= k:
+        init = 'random'
+
+    clock0 = time.perf_counter()
+    W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X, k=k, init=init,
+                                    random_state=random_state, project_T_each_iter=project_T_each_iter,
+                                    project_W_each_iter=project_W_each_iter, w_row_sum=w_row_sum,
+                                    t_row_sum=t_row_sum, fix_W=fix_W, fix_T=fix_T, n=n, d=d)
+    if logger.level <= logging.DEBUG:           # nmf.py:366-367 (see the note at the logger)
+        compute_obj_each_iter = True
+
+    sdt = _storage_dtype(X, dtype)
+    eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device)
+    try:
+        eng.upload_X(X)
+        if W_mat is not None:
+            eng.upload_mask(W_mat)
+        eng.set_W(W)
+        eng.set_T(T)
+        eng.set_params(fix_W=fix_W, fix_T=fix_T, project_T_each_iter=project_T_each_iter,
+                       t_row_sum=t_row_sum, w_row_sum=w_row_sum, reset_topic_method=reset_topic_method,
+                       n_resets=n_resets, reg_w_l1=reg_w_l1, reg_w_l2=reg_w_l2, reg_t_l1=reg_t_l1,
+                       reg_t_l2=reg_t_l2, fix_reset_seed=fix_reset_seed)
+
+        host_views = bool(diagnostics) or callable(early_stop)
+
+        def current():
+            return eng.get_W(), eng.get_T()
+
+        for f in diagnostics:
+            rtv['diagnostics'][f.__name__].append(f(X, W, T))
+
+        iter_cputime, obj_history = [], []
+        last_score = np.inf
+        rolled_back = False
+        if early_stop:
+            eng.snapshot()
+
+        for iter_no in range(max_iter):
+            if early_stop:                       # nmf.py:381-407
+                if callable(early_stop):
+                    Wh, Th = current()
+                    this_score = early_stop(X, Wh, Th)
+                elif compute_obj_each_iter:
+                    this_score = np.inf if not obj_history else obj_history[-1]
+                logger.info('Iter %d stopping score %.3f' % (iter_no, this_score))
+                if this_score > last_score:
+                    eng.rollback()
+                    rolled_back = True
+                    obj_history = obj_history[:-1]
+                    iter_cputime = iter_cputime[:-1]
+                    for f in diagnostics:
+                        rtv['diagnostics'][f.__name__] = rtv['diagnostics'][f.__name__][:-1]
+                    break
+                last_score = this_score
+                eng.snapshot()
+
+            sweep_t0 = time.time()
+            eng.sweep(1)                          # the topic loop, nmf.py:415-476
+
+            if project_W_each_iter and not fix_W and w_row_sum is not None:   # nmf.py:481-484
+                eng.project_W_rows(w_row_sum if np.isscalar(w_row_sum) else w_row_sum.ravel())
+            if compute_obj_each_iter:
+                obj_history.append(eng.objective())
+                logger.info('\tObj: {0:3.3e}'.format(obj_history[-1]))
+            iter_cputime.append(time.perf_counter())
+            if diagnostics:
+                Wh, Th = current()
+                for f in diagnostics:
+                    rtv['diagnostics'][f.__name__].append(f(X, Wh, Th))
+            logger.info('\tTime: %.3fsec' % (time.time() - sweep_t0))
+            if time.time() - wall0 >= max_time:
+                logger.info('STOPPING because max_time after iter %d' % iter_no)
+                break
+            if compute_obj_each_iter and universal_stopping_condition(obj_history, eps_stop=eps_stop):
+                logger.info('STOPPING because obj_history after iter %d' % iter_no)
+                break
+
+        iter_cputime = [c - clock0 for c in iter_cputime]
+
+        # final row-wise projection of W (nmf.py:519-529)
+        if not project_W_each_iter and w_row_sum is not None and not fix_W and do_final_project_W:
+            eng.project_W_rows(w_row_sum if np.isscalar(w_row_sum) else w_row_sum.ravel())
+
+        W, T = current()
+        n_resets_used = eng.n_resets_used
+    finally:
+        eng.close()
+    del host_views, rolled_back
+
+    if w_row is not None:                        # nmf.py:531-539: refit W on the unweighted rows
+        sub = nmf(X_orig, k, T_in=T, fix_T=True, max_iter=10, w_row_sum=w_row_sum,
+                  project_W_each_iter=True, compute_obj_each_iter=compute_obj_each_iter,
+                  dtype=dtype, device=device)
+        obj_history.extend(sub.get('obj_history', []))
+        iter_cputime.extend(sub['iter_cputime'])
+        W = sub['W']
+
+    rtv['W'] = W
+    rtv['T'] = T
+    if compute_obj_each_iter:
+        rtv['obj_history'] = obj_history
+        calc = TrueObjComputer(X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, W_mat, w_row,
+                               dtype=dtype, device=device)
+        calc.obj = obj_history[-1] if obj_history else np.inf
+        rtv['obj_calculator'] = calc
+    rtv['iter_cputime'] = iter_cputime
+    rtv['random_state'] = random_state
+    rtv['n_resets_used'] = n_resets_used
+    return rtv

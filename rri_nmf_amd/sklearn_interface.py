@@ -1,0 +1,206 @@
+"""sklearn-style estimators over nmf() -- same classes, constructor arguments and methods as the
+reference's src/rri_nmf/sklearn_interface.py (NMF_RS_Estimator :14-182, NMF_TM_Estimator :185-345),
+so `fit / fit_transform / one_iter / transform / predict / score` keep working while the solver
+underneath runs on the MI355X.
+"""
+import numpy as np
+import scipy.sparse as sp
+import sklearn.base
+from sklearn.model_selection import train_test_split
+from sklearn.utils.validation import check_X_y, check_array
+
+from . import nmf as _nmf_module
+from .matrixops import tfidf, normalize
+
+
+def _nmf(*a, **kw):
+    return _nmf_module.nmf(*a, **kw)
+
+
+class _FactorPair(object):
+    """W / T storage shared by both estimators (sparsify / densify: :42-57, :230-245)."""
+
+    def sparsify(self):
+        self.W = self.W.tocsr() if sp.issparse(self.W) else sp.csr_matrix(self.W)
+        self.T = self.T.tocsr() if sp.issparse(self.T) else sp.csr_matrix(self.T)
+
+    def densify(self):
+        if sp.issparse(self.W):
+            self.W = self.W.toarray()
+        if sp.issparse(self.T):
+            self.T = self.T.toarray()
+
+    def _warm_start(self):
+        """the estimator's own factors continue a fit (:105-112, :254-261)"""
+        return (self.W if self.W.size > 0 else []), (self.T if self.T.size > 0 else [])
+
+    def _keep(self, soln):
+        self.W = soln.pop('W')
+        self.T = soln.pop('T')
+        self.nmf_outputs = soln
+
+
+def _observed_mask(X):
+    M = np.zeros(X.shape)
+    M[X.nonzero()] = 1
+    return M
+
+
+class NMF_RS_Estimator(_FactorPair, sklearn.base.BaseEstimator):
+    """Recommender flavour: elementwise-weighted RRI (WRRI) on the observed entries, T entries
+    clipped to [0, 1], optional early stopping on a 5 % hold-out (sklearn_interface.py:14-182)."""
+
+    def __init__(self, n, d, k, wr1=0, tr1=0, random_state=0,
+                 W=np.array([]), T=np.array([]), max_iter=30, nmf_kwargs={},
+                 use_validation_early_stopping=True):
+        self.n, self.d, self.k = n, d, k
+        self.max_iter = max_iter
+        self.wr1, self.tr1 = wr1, tr1
+        self.random_state = random_state
+        self.min_rating = None
+        self.max_rating = None
+        self.Xpred = np.array([])
+        self.use_validation_early_stopping = use_validation_early_stopping
+        self.W, self.T = W, T
+        self.nmf_kwargs = nmf_kwargs
+
+    def fit(self, X, y=None):
+        """X: (m, 2) index pairs (i, j); y: the m observed values X[i, j]."""
+        X, y = check_X_y(X, y)
+        self.min_rating, self.max_rating = np.min(y), np.max(y)
+        shape = (self.n, self.d)
+        if self.use_validation_early_stopping:
+            ij_tr, ij_val, r_tr, r_val = train_test_split(X, y, test_size=0.05, random_state=0,
+                                                          stratify=None)
+            Xtr = sp.coo_matrix((r_tr, (ij_tr[:, 0], ij_tr[:, 1])), shape=shape).toarray()
+            Xv = sp.coo_matrix((r_val, (ij_val[:, 0], ij_val[:, 1])), shape=shape).toarray()
+            vi, vj = Xv.nonzero()
+            lo, hi = self.min_rating, self.max_rating
+
+            def RMSE_val(X_ignored, W, T):
+                pred = np.clip(np.dot(W, T), lo, hi)
+                return np.sqrt(np.mean((pred[vi, vj] - Xv[vi, vj]) ** 2))
+
+            self.early_stop = RMSE_val
+        else:
+            self.early_stop = False
+            Xtr = sp.coo_matrix((y, (X[:, 0], X[:, 1])), shape=shape).toarray()
+        W_in, T_in = self._warm_start()
+        soln = _nmf(Xtr, self.k, max_iter=self.max_iter, max_time=7200, compute_obj_each_iter=True,
+                    reset_topic_method=None, early_stop=self.early_stop, project_T_each_iter=False,
+                    t_row_sum=1.0, project_W_each_iter=False, w_row_sum=None,
+                    W_mat=_observed_mask(Xtr), W_in=W_in, T_in=T_in, reg_w_l1=self.wr1,
+                    reg_t_l1=self.tr1, random_state=self.random_state, **self.nmf_kwargs)
+        self._keep(soln)
+        return self
+
+    def fit_from_Xtr(self, Xtr):
+        """builds the (index pairs, values) lists from a ratings matrix and fits"""
+        Xtr = Xtr.tocsr() if sp.issparse(Xtr) else sp.csr_matrix(Xtr)
+        rows, cols = Xtr.nonzero()
+        return self.fit(np.column_stack((rows, cols)), Xtr.data)
+
+    def transform(self, Xnew):
+        """fold new rows in against the fitted T"""
+        soln = _nmf(Xnew, self.k, max_iter=4, max_time=7200, project_W_each_iter=False,
+                    project_T_each_iter=False, W_mat=_observed_mask(Xnew), T_in=self.T, fix_T=True,
+                    reg_w_l1=self.wr1, reg_t_l1=self.tr1, t_row_sum=1.0, w_row_sum=None,
+                    reset_topic_method='random', random_state=self.random_state, **self.nmf_kwargs)
+        return soln['W']
+
+    def make_Xpred(self):
+        if self.Xpred.size == 0:
+            self.Xpred = np.clip(np.dot(self.W, self.T), a_min=self.min_rating, a_max=self.max_rating)
+
+    def predict(self, X):
+        self.make_Xpred()
+        X = check_array(X)
+        # the reference indexes with the float array check_array returns, which modern numpy rejects
+        idx = np.asarray(X, dtype=np.intp)
+        return self.Xpred[idx[:, 0], idx[:, 1]]
+
+    def score(self, X, y=np.array([])):
+        """RMSE of the clipped reconstruction on the given entries"""
+        self.make_Xpred()
+        if sp.issparse(X):
+            X = X.toarray()
+        if y.size > 0:
+            return np.sqrt(np.mean((y - self.predict(X)) ** 2))
+        i, j = X.nonzero()
+        return np.sqrt(np.mean((X[i, j] - self.Xpred[i, j]) ** 2))
+
+
+class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.TransformerMixin):
+    """Topic-model flavour: rows of T on the simplex after every update, rows of W projected at the
+    end (sklearn_interface.py:185-345).
+
+    n, d, k: documents, dictionary size, topics; wr1/wr2/tr1/tr2: l1/l2 penalties on W and T;
+    handle_tfidf / handle_normalization: preprocess X inside fit/transform; W, T: optional warm
+    start; nmf_kwargs: extra keyword arguments for nmf()."""
+
+    def __init__(self, n, d, k, wr1=0, wr2=0, tr1=0, tr2=0, random_state=0,
+                 handle_tfidf=False, handle_normalization=False, max_iter=300,
+                 W=np.array([]), T=np.array([]), nmf_kwargs={},
+                 do_final_project_W=True):
+        self.n, self.d, self.k = n, d, k
+        self.wr1, self.wr2, self.tr1, self.tr2 = wr1, wr2, tr1, tr2
+        self.random_state = random_state
+        self.handle_tfidf = handle_tfidf
+        self.handle_normalization = handle_normalization
+        self.max_iter = max_iter
+        self.W, self.T = W, T
+        self.nmf_kwargs = nmf_kwargs
+        self.do_final_project_W = do_final_project_W
+
+    def _prepare_fit(self, X):
+        if self.handle_tfidf:
+            X, self.idf = tfidf(X, return_idf=True)
+        if self.handle_normalization:
+            X = normalize(X)
+        return X
+
+    def _solve(self, X, max_iter, max_time):
+        W_in, T_in = self._warm_start()
+        X = self._prepare_fit(X)
+        soln = _nmf(X, self.k, max_iter=max_iter, max_time=max_time, project_W_each_iter=False,
+                    w_row_sum=1.0, project_T_each_iter=True, t_row_sum=1.0,
+                    do_final_project_W=self.do_final_project_W, W_in=W_in, T_in=T_in,
+                    reg_w_l1=self.wr1, reg_w_l2=self.wr2, reg_t_l1=self.tr1, reg_t_l2=self.tr2,
+                    random_state=self.random_state, **self.nmf_kwargs)
+        self._keep(soln)
+
+    def fit_transform(self, X, y=None):
+        assert np.all(X >= 0), 'X must be non-negative'
+        self._solve(X, self.max_iter, 7200)
+        return self.W
+
+    def fit(self, X, y=None):
+        self.fit_transform(X, y)
+        return self
+
+    def one_iter(self, X):
+        """one more sweep from the estimator's current factors"""
+        self._solve(X, 1, 240)
+        return self
+
+    def transform(self, Xnew):
+        """express Xnew in the fitted topics (4 sweeps over W with T fixed)"""
+        if self.handle_tfidf:
+            Xnew = Xnew * self.idf
+        if self.handle_normalization:
+            Xnew = normalize(Xnew)
+        soln = _nmf(Xnew, self.k, max_iter=4, max_time=7200, project_W_each_iter=False, w_row_sum=1.0,
+                    t_row_sum=1.0, T_in=self.T, do_final_project_W=self.do_final_project_W, fix_T=True,
+                    reg_w_l1=self.wr1, reg_w_l2=self.wr2, reg_t_l1=self.tr1, reg_t_l2=self.tr2,
+                    random_state=self.random_state)
+        return soln['W']
+
+    def constrained_transform(self, X):
+        return self.transform(X)
+
+    def score(self, X, y=None):
+        """R^2 of the reconstruction of new documents"""
+        sst = ((X - np.mean(X, axis=0)) ** 2).sum()
+        W = self.transform(X)
+        sse = ((X - np.dot(W, self.T)) ** 2).sum()
+        return 1 - sse / sst

@@ -1,0 +1,207 @@
+"""CPU-only tests: the C-ABI surface, the host logic of nmf() that runs before any device work, the
+host helper modules, and the estimators' plumbing (with the oracle standing in for the solver)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, relfro
+from oracle import rri_oracle as orc
+from rri_nmf_amd import _capi, matrixops, optimization
+from rri_nmf_amd.synthetic import planted_X, scaled_init
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'rri_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(rri_[A-Za-z0-9_]+)\s*\(', text)))
+
+
+def gpu_present():
+    lib = _capi.load_library()
+    h = ctypes.c_void_p()
+    st = lib.rri_create(ctypes.byref(h), 4, 4, 2, 0, 0, 0, None)
+    if st == 0:
+        lib.rri_destroy(h)
+    return st == 0
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 35
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for nm in names:
+        assert hasattr(lib, nm), 'librri_hip.so lacks %s declared in include/rri_hip.h' % nm
+    assert sorted(_capi.PROTOTYPES) == names, 'ctypes binding and header disagree'
+    typed = _capi.load_library()
+    assert typed.rri_abi_version() == _capi.ABI_VERSION
+
+
+def test_abi_struct_layout_matches_header():
+    assert ctypes.sizeof(_capi.Params) == 8 * 4 + 7 * 8
+    assert ctypes.sizeof(_capi.Event) == 16
+    assert _capi.Params.t_row_sum.offset == 32 and _capi.Params.eps_div.offset == 80
+
+
+def test_null_and_bad_arguments_are_rejected_without_a_gpu():
+    lib = _capi.load_library()
+    assert lib.rri_create(None, 4, 4, 2, 0, 0, 0, None) == _capi.RRI_ERR_INVALID
+    h = ctypes.c_void_p()
+    assert lib.rri_create(ctypes.byref(h), 0, 4, 2, 0, 0, 0, None) == _capi.RRI_ERR_INVALID
+    assert b'n,d,k' in lib.rri_last_error(None)
+    assert lib.rri_create(ctypes.byref(h), 4, 4, 2, 7, 0, 0, None) == _capi.RRI_ERR_INVALID
+    assert lib.rri_sweep(None, 1, None) == _capi.RRI_ERR_INVALID
+    assert lib.rri_destroy(None) == _capi.RRI_OK
+
+
+def test_no_cpu_fallback():
+    """without a GPU the product path must fail loudly, never compute on the host"""
+    if gpu_present():
+        pytest.skip('a GPU is visible here')
+    from rri_nmf_amd.nmf import nmf
+    from rri_nmf_amd.engine import RRIEngine
+    X = planted_X(30, 20, 3, dtype=np.float64)
+    W0, T0 = scaled_init(X, 3)
+    with pytest.raises(_capi.RRIHipUnavailable):
+        RRIEngine(30, 20, 3)
+    with pytest.raises(_capi.RRIHipUnavailable):
+        nmf(X, 3, W_in=W0, T_in=T0, max_iter=2)
+    with pytest.raises(_capi.RRIHipUnavailable):
+        _capi.load_library('/nonexistent/librri_hip.so')
+
+
+def test_nmf_host_checks_before_device_work():
+    """argument handling that the reference performs before its loop (nmf.py:280-315, 853-860)"""
+    from rri_nmf_amd.nmf import nmf
+    g = load_golden('g6_rare_branches')
+    X = planted_X(30, 20, 3, dtype=np.float64)
+    W0, T0 = scaled_init(X, 3)
+    s1 = nmf(X, 3, W_in=W0, T_in=T0, reg_t_l2=-1.0)      # unbounded in T -> sentinel, no exception
+    assert s1['obj_history'] == [-np.inf] and s1['iter_cputime'] == [0]
+    assert np.array_equal(s1['W'][:2, :2], g['sent_T_W']) and np.array_equal(s1['T'][:2, :2], g['sent_T_T'])
+    s2 = nmf(X, 3, W_in=W0, T_in=T0, reg_w_l1=-1.0)
+    assert np.array_equal(s2['W'][:2, :2], g['sent_W_W']) and np.array_equal(s2['T'][:2, :2], g['sent_W_T'])
+    with pytest.raises(ValueError, match='W_in has wrong dimensions'):
+        nmf(X, 3, W_in=W0[:, :2], T_in=T0)
+    with pytest.raises(ValueError, match='T_in has wrong dimensions'):
+        nmf(X, 3, W_in=W0, T_in=T0[:, :5])
+    with pytest.raises(NotImplementedError):
+        nmf(X, 3, W_in=W0, T_in=T0, store_gradients=True)
+    with pytest.raises(NotImplementedError):
+        nmf(X, 3, W_in=W0, T_in=T0, eps_gauss_t=1.0, delta_gauss_t=0.1)
+    Wkeep, Tkeep = W0.copy(), T0.copy()
+    assert np.array_equal(W0, Wkeep) and np.array_equal(T0, Tkeep)   # caller arrays untouched
+
+
+def test_signature_is_the_references():
+    import inspect
+    from rri_nmf_amd.nmf import nmf
+    want = ['X', 'k', 'w_row', 'W_mat', 'fix_W', 'fix_T', 'random_state', 'init', 'T_in', 'W_in', 'max_iter',
+            'max_time', 'eps_stop', 'compute_obj_each_iter', 'project_W_each_iter', 'w_row_sum',
+            'do_final_project_W', 'project_T_each_iter', 't_row_sum', 'early_stop', 'reset_topic_method',
+            'fix_reset_seed', 'n_resets', 'reg_w_l2', 'reg_t_l2', 'reg_w_l1', 'reg_t_l1', 'diagnostics',
+            'store_gradients', 'ind_rows_to_store', 'eps_gauss_t', 'delta_gauss_t']
+    sig = inspect.signature(nmf)
+    pos = [p.name for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert pos == want                                        # nmf.py:98-108
+    d = {p.name: p.default for p in sig.parameters.values()}
+    assert (d['max_iter'], d['max_time'], d['eps_stop'], d['n_resets'], d['init']) == (200, 600, 1e-4, 23, 'nndsvd')
+    assert d['reset_topic_method'] == 'max_resid_document' and d['do_final_project_W'] is True
+
+
+def test_matrixops_match_oracle():
+    g = load_golden('g7_functions')
+    for nm in ('rand', 'pos', 'zeros', 'onsimplex', 'ties', 'single', 'neg', 'big'):
+        v = g['proj_in_' + nm]
+        for s in (1.0, 2.5):
+            assert np.array_equal(matrixops.euclidean_proj_simplex(v.copy(), s), g['proj_out_%s_s%g' % (nm, s)])
+    rs = np.random.RandomState(0)
+    A = rs.rand(7, 5)
+    A[3] = 0
+    assert np.array_equal(matrixops.normalize(A.copy()), orc.normalize(A.copy()))
+    assert np.array_equal(matrixops.normalize(A.copy(), 0), orc.normalize(A.copy(), 0))
+    assert np.array_equal(matrixops.tfidf(A.copy()), orc.tfidf(A.copy()))
+    B = rs.randn(6, 4)
+    assert np.array_equal(matrixops.proj_mat_to_simplex(B.copy(), 1.0), orc.proj_rows_simplex(B.copy(), 1.0))
+    sv = np.array([1.0, 2.0, 0.5, 1.0, 3.0, 1.0])
+    assert np.array_equal(matrixops.proj_mat_to_simplex(B.copy(), sv), orc.proj_rows_simplex(B.copy(), sv))
+    assert np.array_equal(matrixops.proj_mat_to_simplex(B.copy(), 1.0, axis=0), orc.proj_rows_simplex(B.copy(), 1.0, axis=0))
+    H = matrixops.harden_distributions(A)
+    assert H.sum() == 7 and np.array_equal(np.argmax(H, 1), np.argmax(A, 1))
+    assert matrixops.labels_to_mat(np.array([0, 2, 1, 2])).tolist() == [[1, 0, 0], [0, 0, 1], [0, 1, 0], [0, 0, 1]]
+    assert matrixops.stack_matrices([A, A]).shape == (14, 5) and matrixops.stack_matrices([A, A], dim='fat').shape == (7, 10)
+    assert np.allclose((matrixops.normalize_l2(A + 1) ** 2).sum(1), 1, atol=1e-9)
+
+
+def test_stop_rules_and_init():
+    g = load_golden('g7_functions')
+    hist = [10.0, 8.0, 7.5, 7.4999]
+    usc = optimization.universal_stopping_condition
+    assert np.array_equal(np.array([usc(hist[:1]), usc(hist[:2]), usc(hist[:3]), usc(hist), usc(hist, -1)]), g['usc'])
+    assert optimization.first_last_stopping_condition([10.0, 1e-4], 1e-4) and not optimization.first_last_stopping_condition([10.0], 1)
+    from rri_nmf_amd.initialization import initialize_nmf
+    g8 = load_golden('g8_init')                          # the reference's test_init (tests/test_nmf.py:13-19)
+    W, T = initialize_nmf(g8['X'], 2, init='nndsvd', random_state=0)
+    assert np.allclose(g8['W_expected'], W) and np.allclose(g8['T_expected'], T)
+    for init in ('random', 'smart_random', 'nndsvda', 'nndsvdar'):
+        X = planted_X(40, 30, 4, dtype=np.float64)
+        a = initialize_nmf(X, 4, init=init, random_state=3)
+        b = orc.initialize_nmf(X, 4, init=init, random_state=3)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), init
+    with pytest.raises(ValueError):
+        initialize_nmf(planted_X(10, 8, 2, dtype=np.float64), 2, init='coherence_pmi')
+
+
+def test_initialize_and_validate_matches_oracle():
+    from rri_nmf_amd.nmf import _initialize_and_validate
+    X = planted_X(50, 40, 4, dtype=np.float64)
+    for kw in (dict(project_T_each_iter=True, project_W_each_iter=True, w_row_sum=1.0, t_row_sum=1.0),
+               dict(project_T_each_iter=False, project_W_each_iter=False, w_row_sum=None, t_row_sum=1.0),
+               dict(project_T_each_iter=True, project_W_each_iter=False, w_row_sum=1.0, t_row_sum=1.0)):
+        a = _initialize_and_validate(W_in=[], T_in=[], W_mat=None, X=X, k=4, init='nndsvd', random_state=0,
+                                     fix_W=False, fix_T=False, n=50, d=40, **kw)
+        b = orc.initialize_and_validate(X, 4, [], [], None, 'nndsvd', 0, kw['project_T_each_iter'],
+                                        kw['project_W_each_iter'], kw['w_row_sum'], kw['t_row_sum'], False, False)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_estimator_plumbing_with_oracle_solver(monkeypatch):
+    """the estimators' flag sets / warm starts / one_iter resumability (tests/test_nmf.py:90-110),
+    with the CPU oracle substituted for the device solver"""
+    import scipy.sparse as sp
+    from rri_nmf_amd import sklearn_interface as si
+    from rri_nmf_amd.matrixops import proj_mat_to_simplex
+
+    def oracle_nmf(*a, **kw):
+        kw.setdefault('objective_always', True)   # the reference as shipped
+        return orc.nmf(*a, **kw)
+    monkeypatch.setattr(si._nmf_module, 'nmf', oracle_nmf)
+    g = load_golden('g1_tm_estimator')
+    X = g['X']
+    n, d = X.shape
+    M = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=10).fit(X)
+    assert relfro(M.W, g['W_shipped']) < 1e-8 and relfro(M.T, g['T_shipped']) < 1e-8
+    assert np.linalg.norm(X - M.W @ M.T) < np.linalg.norm(X)
+    M2 = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=2, do_final_project_W=False).fit(X)
+    M2.max_iter = 10
+    for _ in range(8):
+        M2 = M2.one_iter(X)
+    M2.W = proj_mat_to_simplex(M2.W)
+    assert np.allclose(M2.T, M.T) and np.allclose(M2.W, M.W)
+    Wte = M.transform(g['Xte'])
+    assert Wte.shape == (g['Xte'].shape[0], 5) and abs(M.score(g['Xte']) - float(g['score_te'])) < 1.0
+    # recommender estimator against the reference's vectors
+    g4 = load_golden('g4_wrri')
+    R = g4['X']
+    E = si.NMF_RS_Estimator(R.shape[0], R.shape[1], 5, random_state=0, max_iter=20).fit_from_Xtr(R)
+    assert abs(E.score(R) - float(g4['rs_es_score'])) < 1e-6 and E.score(R) < 1.0   # tests/test_nmf.py:88
+    assert len(E.nmf_outputs['obj_history']) == len(g4['rs_es_obj'])
+    E2 = si.NMF_RS_Estimator(R.shape[0], R.shape[1], 5, random_state=0, max_iter=20,
+                             use_validation_early_stopping=False).fit_from_Xtr(sp.csr_matrix(R))
+    assert abs(E2.score(R) - float(g4['rs_noes_score'])) < 1e-6
+    i, j = R.nonzero()
+    pred = E2.predict(np.column_stack((i, j)).astype(float))
+    assert pred.shape == i.shape and abs(E2.score(np.column_stack((i, j)), R[i, j]) - E2.score(R)) < 1e-12
+    E2.sparsify(); assert sp.issparse(E2.W); E2.densify(); assert isinstance(E2.W, np.ndarray)

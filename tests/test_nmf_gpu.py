@@ -1,0 +1,190 @@
+"""GPU tests of the drop-in surface: nmf() and the estimators on the reference's own fixtures, following
+the reference's test file (tests/test_nmf.py) case by case, plus comparisons with the vectors captured
+from the reference and with the oracle."""
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relfro
+from rri_nmf_amd.synthetic import planted_X, scaled_init
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-9   # see tests/test_hip_parity.py for how this bound is derived
+
+
+def api():
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd import sklearn_interface as si
+    return nmf_mod, si
+
+
+def oracle():
+    from oracle import rri_oracle
+    return rri_oracle
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+def test_convergence_tm_setting(ci):
+    """tests/test_nmf.py:22-42: objective non-increasing, W and T rows on the simplex"""
+    nmf_mod, _ = api()
+    g = load_golden('g3_tm_settings')
+    cases = [{'k': 25}, {'k': 15, 'reg_t_l2': 0.1}, {'k': 15, 'reg_t_l2': -0.1}, {'k': 15, 'reg_w_l2': 0.1}]
+    p = dict(cases[ci], max_iter=15, w_row_sum=1.0, random_state=0, eps_stop=1e-4, project_T_each_iter=True,
+             project_W_each_iter=True, compute_obj_each_iter=True, t_row_sum=1.0, early_stop=False)
+    X = g['X']
+    soln = nmf_mod.nmf(X, **p)                       # own NNDSVD start, as the reference's test does
+    oh = np.array(soln['obj_history'])
+    assert np.all(np.diff(oh) <= 1e-12 * abs(oh[0]))
+    W, T = soln['W'], soln['T']
+    assert W.min() >= -1e-13 and T.min() >= -1e-13
+    assert np.sum(np.abs(W.sum(1) - 1)) + np.sum(np.abs(T.sum(1) - 1)) <= 1e-11
+    # and the reference's numbers, from the reference's starting point
+    soln = nmf_mod.nmf(X, W_in=g['c%d_W0' % ci], T_in=g['c%d_T0' % ci], **p)
+    assert relfro(soln['W'], g['c%d_W' % ci]) < 1e-7 and relfro(soln['T'], g['c%d_T' % ci]) < 1e-7
+    want = g['c%d_obj' % ci]
+    assert len(soln['obj_history']) == len(want)
+    assert np.allclose(soln['obj_history'], want, rtol=1e-9)
+
+
+def test_convergence_TM_Estimator():
+    """tests/test_nmf.py:90-110"""
+    _, si = api()
+    from rri_nmf_amd.matrixops import proj_mat_to_simplex
+    g = load_golden('g1_tm_estimator')
+    X = g['X']
+    n, d = X.shape
+    M = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=10).fit(X)
+    assert np.linalg.norm(X - np.dot(M.W, M.T), 'fro') < np.linalg.norm(X, 'fro')
+    # as shipped the reference tracks the objective and applies its stop rule: same sweeps, same result
+    assert len(M.nmf_outputs['obj_history']) == len(g['obj_shipped'])
+    assert np.allclose(M.nmf_outputs['obj_history'], g['obj_shipped'], rtol=1e-9)
+    assert relfro(M.W, g['W_shipped']) < 1e-7 and relfro(M.T, g['T_shipped']) < 1e-7
+    assert np.array_equal(np.argmax(M.W, 1), np.argmax(g['W_shipped'], 1))
+    M2 = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=2, do_final_project_W=False).fit(X)
+    M2.max_iter = 10
+    for _ in range(7):
+        M2 = M2.one_iter(X)
+    M2 = M2.one_iter(X)
+    M2.W = proj_mat_to_simplex(M2.W)
+    assert np.allclose(M2.T, M.T) and np.allclose(M2.W, M.W)
+    # fold-in and R^2 on the held-out documents
+    M3 = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=10, nmf_kwargs={'eps_stop': -1}).fit(X)
+    Wte = M3.transform(g['Xte'])
+    assert relfro(Wte, g['Wte']) < 1e-7 and np.array_equal(np.argmax(Wte, 1), g['argmax_te'])
+    assert abs(M3.score(g['Xte']) - float(g['score_te'])) < 1e-9
+    assert Wte is not None and M3.constrained_transform(g['Xte']).shape == Wte.shape
+
+
+def test_logger_level_switches_objective_tracking():
+    nmf_mod, _ = api()
+    X = planted_X(200, 120, 4, dtype=np.float64)
+    W0, T0 = scaled_init(X, 4)
+    old = nmf_mod.logger.level
+    try:
+        nmf_mod.logger.setLevel(logging.WARNING)
+        r = nmf_mod.nmf(X, 4, W_in=W0, T_in=T0, max_iter=3)
+        assert 'obj_history' not in r and len(r['iter_cputime']) == 3
+        nmf_mod.logger.setLevel(logging.NOTSET)
+        r = nmf_mod.nmf(X, 4, W_in=W0, T_in=T0, max_iter=3, eps_stop=-1)
+        assert len(r['obj_history']) == 3 and r['obj_calculator'].obj == r['obj_history'][-1]
+        assert abs(r['obj_calculator'].true_objective() - r['obj_history'][-1]) <= 1e-12 * r['obj_history'][-1]
+    finally:
+        nmf_mod.logger.setLevel(old)
+
+
+def test_options_against_oracle():
+    nmf_mod, _ = api()
+    orc = oracle()
+    n, d, k = 400, 150, 6
+    X = planted_X(n, d, k, seed=3, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=4)
+    Xn = orc.normalize(X.copy())
+
+    def both(Xa, **kw):
+        a = nmf_mod.nmf(Xa, k, W_in=W0, T_in=T0, **kw)
+        b = orc.nmf(Xa, k, W_in=W0.copy(), T_in=T0.copy(), objective_always=True, **kw)
+        return a, b
+
+    # each-sweep W projection + stop rule (same number of sweeps)
+    a, b = both(Xn, max_iter=40, eps_stop=1e-3, project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0,
+                project_W_each_iter=True)
+    assert len(a['obj_history']) == len(b['obj_history']) < 40
+    assert relfro(a['W'], b['W']) < 1e-7 and relfro(a['T'], b['T']) < 1e-7
+    # early stopping on a callable score with rollback, diagnostics recorded per sweep
+    hold = (np.random.RandomState(0).rand(n, d) < 0.1)
+
+    def val_score(Xi, W, T):
+        return float(np.sqrt(np.mean(((W @ T) - X)[hold] ** 2))) * (1 if W.sum() < 1e9 else 1)
+
+    def recon(Xi, W, T):
+        return float(np.linalg.norm(Xi - W @ T))
+    noisy = X * (~hold) + hold * X.mean()
+    a, b = both(noisy, max_iter=25, eps_stop=-1, early_stop=val_score, diagnostics=[recon])
+    assert len(a['iter_cputime']) == len(b['iter_cputime'])
+    assert relfro(a['W'], b['W']) < 1e-7 and relfro(a['T'], b['T']) < 1e-7
+    assert np.allclose(a['diagnostics']['recon'], b['diagnostics']['recon'], rtol=1e-8)
+    # per-row weights with the recursive refit of W (nmf.py:335-344, 531-539)
+    wr = np.random.RandomState(1).rand(n, 1) + 0.5
+    a, b = both(Xn, max_iter=4, eps_stop=-1, w_row=wr, w_row_sum=wr.copy(), project_T_each_iter=True,
+                t_row_sum=1.0)
+    assert relfro(a['W'], b['W']) < 1e-7 and relfro(a['T'], b['T']) < 1e-7
+    # float32 storage of X, float64 arithmetic: compared with the oracle on the same fp32-valued X
+    X32 = X.astype(np.float32)
+    a = nmf_mod.nmf(X32, k, W_in=W0, T_in=T0, max_iter=6, eps_stop=-1)
+    b = orc.nmf(X32.astype(np.float64), k, W_in=W0.copy(), T_in=T0.copy(), max_iter=6, eps_stop=-1)
+    assert relfro(a['W'], b['W']) < TOL and relfro(a['T'], b['T']) < TOL and a['W'].dtype == np.float64
+
+
+def test_errors_raised_like_the_reference():
+    nmf_mod, _ = api()
+    g = load_golden('g6_rare_branches')
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=3, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=4)
+    Wd = g['dead_W0']
+    with pytest.raises(ValueError, match='unbounded'):
+        nmf_mod.nmf(X, k, W_in=Wd, T_in=T0, max_iter=2, eps_stop=-1)
+    with pytest.raises(AssertionError, match='sums to 0'):
+        nmf_mod.nmf(X, k, W_in=Wd, T_in=T0, max_iter=2, eps_stop=-1, t_row_sum=1.0, w_row_sum=1.0,
+                    do_final_project_W=False, reset_topic_method=None)
+    r = nmf_mod.nmf(X, k, W_in=Wd, T_in=T0, max_iter=2, eps_stop=-1, t_row_sum=1.0)
+    assert r['n_resets_used'] >= 1 and relfro(r['T'], g['dead_mrd_T']) < 1e-7
+    with pytest.raises(NotImplementedError):
+        Xn = oracle().normalize(X.copy())
+        nmf_mod.nmf(Xn, k, W_in=W0, T_in=T0, max_iter=2, project_T_each_iter=True, t_row_sum=2.0,
+                    w_row_sum=1.0, reg_t_l2=-50.0)
+
+
+def test_sharded_stepping_single_rank_matches_sweep():
+    """the split step protocol (reduce -> [all-reduce] -> finish) gives what rri_sweep gives; run with a
+    one-rank gloo group so the collective is exercised on the engine's torch stream"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = 3000, 1100, 5
+    X = planted_X(n, d, k, seed=0, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=1)
+    with RRIEngine(n, d, k, dtype=np.float32) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params()
+        e.sweep(3)
+        Wa, Ta, obja = e.get_W(), e.get_T(), e.objective()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29617')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        eng, red, stream = make_device_shard(n, d, k, dtype=np.float32, device_index=0)
+        eng.upload_X(X); eng.set_W(W0); eng.set_T(T0); eng.set_params()
+        drv = ShardedRRI(eng, red, k, stream=stream)
+        drv.sweep(2)
+        drv.sweep(1)
+        Wb, Tb = eng.get_W(), eng.get_T()
+        objb = drv.objective()
+        assert drv.allreduce_calls == 3 * k + 2
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ta, Tb)
+    assert abs(obja - objb) <= 1e-12 * abs(obja)

@@ -80,28 +80,35 @@ def device_planted_shard(n_rows, d, k, seed, device):
     return X
 
 
-def cpu_baseline(Xs_host, W0s, T0, n_full, sweeps=2):
-    """the numpy float64 restatement on the host cores: 1 warm-up + `sweeps` timed sweeps on the sample"""
+def cpu_baseline(Xs_host, W0s, T0, n_full, sweeps=2, threads=16):
+    """the numpy float64 restatement on the host cores: 1 warm-up + `sweeps` timed sweeps on the sample.
+    BLAS threads are capped at the box's CPU share for one GPU (16).  Also returns how far the SAME
+    restatement moves when its start is perturbed by one ulp: the iteration's own sensitivity, which
+    bounds the agreement any two implementations (or two BLAS builds) can show."""
     import numpy as np
     from oracle import rri_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:  # noqa: BLE001
-        threads = os.cpu_count() or 1
+    from threadpoolctl import threadpool_limits
+    threads = int(min(threads, os.cpu_count() or threads))
     X = Xs_host.astype(np.float64)
     W, T = W0s.astype(np.float64).copy(), T0.astype(np.float64).copy()
-    orc.plain_sweeps(X, W, T, 1)
-    t0 = time.perf_counter()
-    orc.plain_sweeps(X, W, T, sweeps)
-    dt = time.perf_counter() - t0
+    with threadpool_limits(limits=threads):
+        orc.plain_sweeps(X, W, T, 1)
+        t0 = time.perf_counter()
+        orc.plain_sweeps(X, W, T, sweeps)
+        dt = time.perf_counter() - t0
+        Wp = W0s.astype(np.float64) * (1.0 + 2.0 ** -52 * np.sign(np.random.RandomState(7).randn(*W0s.shape)))
+        Tp = T0.astype(np.float64).copy()
+        orc.plain_sweeps(X, Wp, Tp, 1 + sweeps)
     rate_sample = sweeps / dt
     frac = X.shape[0] / float(n_full)
-    return dict(value=rate_sample * frac, unit='sweeps/s', cores=int(threads), kind='port',
+    sens = {'relfro_W': float(np.linalg.norm(Wp - W) / np.linalg.norm(W)),
+            'relfro_T': float(np.linalg.norm(Tp - T) / np.linalg.norm(T)),
+            'what': 'CPU restatement vs itself with W0 perturbed by 1 ulp, same sweeps'}
+    return dict(value=rate_sample * frac, unit='sweeps/s', cores=threads, kind='port',
                 sample='first %d of %d rows of the same X, %d timed sweeps after 1 warm-up, numpy float64 + '
                        'OpenBLAS on %d threads (%d host cpus); sample rate %.3f sweeps/s scaled by %.4g '
                        '(work is linear in n)' % (X.shape[0], n_full, sweeps, threads, os.cpu_count() or 0,
-                                                  rate_sample, frac)), W, T
+                                                  rate_sample, frac)), W, T, sens
 
 
 def main():
@@ -225,7 +232,7 @@ def main():
         if not args.no_cpu_baseline:
             rows = min(args.cpu_rows, n_local)
             Xs = X[:rows].cpu().numpy()
-            cb, Wc, Tc = cpu_baseline(Xs, W0[:rows], T0, n_local)
+            cb, Wc, Tc, sens = cpu_baseline(Xs, W0[:rows], T0, n_local)
             out['cpu_baseline'] = cb
             # parity in the same run: the device path on the same sample, equal sweeps (1 + 2)
             from rri_nmf_amd.engine import RRIEngine
@@ -240,7 +247,8 @@ def main():
                 'sweeps': 3, 'rows': rows,
                 'relfro_W': float(np.linalg.norm(Wg - Wc) / np.linalg.norm(Wc)),
                 'relfro_T': float(np.linalg.norm(Tg - Tc) / np.linalg.norm(Tc)),
-                'relfro_WT': float(np.linalg.norm(Wg @ Tg - Wc @ Tc) / np.linalg.norm(Wc @ Tc))}
+                'relfro_WT': float(np.linalg.norm(Wg @ Tg - Wc @ Tc) / np.linalg.norm(Wc @ Tc)),
+                'reference_self_sensitivity': sens}
             out['gpu_over_cpu'] = value / cb['value'] if cb['value'] else None
     eng.close()
     if world > 1:

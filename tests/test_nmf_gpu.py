@@ -126,7 +126,7 @@ def test_options_against_oracle():
     assert np.allclose(a['diagnostics']['recon'], b['diagnostics']['recon'], rtol=1e-8)
     # per-row weights with the recursive refit of W (nmf.py:335-344, 531-539)
     wr = np.random.RandomState(1).rand(n, 1) + 0.5
-    a, b = both(Xn, max_iter=4, eps_stop=-1, w_row=wr, w_row_sum=wr.copy(), project_T_each_iter=True,
+    a, b = both(Xn, max_iter=4, eps_stop=-1, w_row=wr, w_row_sum=1.0, project_T_each_iter=True,
                 t_row_sum=1.0)
     assert relfro(a['W'], b['W']) < 1e-7 and relfro(a['T'], b['T']) < 1e-7
     # float32 storage of X, float64 arithmetic: compared with the oracle on the same fp32-valued X
@@ -182,7 +182,7 @@ def test_sharded_stepping_single_rank_matches_sweep():
         drv.sweep(1)
         Wb, Tb = eng.get_W(), eng.get_T()
         objb = drv.objective()
-        assert drv.allreduce_calls == 3 * k + 2
+        assert drv.allreduce_calls == 3 * k + 1   # the second call reuses the reduction its predecessor left for topic 0
         eng.close()
     finally:
         dist.destroy_process_group()

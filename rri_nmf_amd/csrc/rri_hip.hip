@@ -168,36 +168,46 @@ struct TimedScope {
 };
 
 // ---- typed launch helpers ------------------------------------------------------------------
-int g_pass_unroll = 4;  // rows in flight per wave in k_pass (env RRI_PASS_UNROLL: 2 or 4)
+// geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
+int g_pass_unroll = 8, g_pass_nt = 1;
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
 template <typename SX>
 struct LaunchX {
-    static size_t pass_shmem(const rri_ctx* c) {
-        return (size_t)4 * 4 * (16 / sizeof(SX)) * 64 * sizeof(double) + 2 * (size_t)c->rpb * sizeof(double);
-    }
-    template <bool DO_Y, bool DO_Z, bool UPD, int U>
-    static void pass_u(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b) {
+    static size_t pass_shmem(const rri_ctx* c) { return 6 * (size_t)c->rpb * sizeof(double); }
+    template <bool DO_Y, bool DO_Z, bool UPD, int U, bool NT>
+    static void pass_k(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
         typedef typename std::conditional<UPD, SX, const SX>::type XT;
-        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U>), dim3(c->npanels * c->nrb), dim3(256), pass_shmem(c),
-                           c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart, c->Zpart, c->LD,
-                           c->rpb, c->npanels, a, b, (const DevState*)c->st);
+        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT>), dim3(c->npanels * c->nrb), dim3(256),
+                           pass_shmem(c), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
+                           c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st);
+    }
+    template <bool DO_Y, bool DO_Z, bool UPD>
+    static void pass_cfg(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a,
+                         const double* b) {
+        const int key = g_pass_unroll * 2 + (g_pass_nt ? 1 : 0);
+        switch (key) {
+#define RRI_CASE(U_)                                                                      \
+    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false>(c, Xp, trow, wc, a, b); break;   \
+    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true>(c, Xp, trow, wc, a, b); break;
+            RRI_CASE(4)
+            RRI_CASE(8)
+            RRI_CASE(16)
+#undef RRI_CASE
+            default: pass_k<DO_Y, DO_Z, UPD, 8, true>(c, Xp, trow, wc, a, b);
+        }
     }
     // row dots against T[t,:] (DO_Y) and column sums against W[:,tz] (DO_Z)
     template <bool DO_Y, bool DO_Z>
     static void pass(rri_ctx* c, int t, int tz) {
         TimedScope ts(c, 0);
-        const double* trow = c->T + (i64)t * c->LD;
-        const double* wc = c->W + (i64)tz * c->ldw;
-        if (g_pass_unroll == 2) pass_u<DO_Y, DO_Z, false, 2>(c, c->X, trow, wc, nullptr, nullptr);
-        else pass_u<DO_Y, DO_Z, false, 4>(c, c->X, trow, wc, nullptr, nullptr);
+        pass_cfg<DO_Y, DO_Z, false>(c, c->X, c->T + (i64)t * c->LD, c->W + (i64)tz * c->ldw, nullptr, nullptr);
     }
     // R <- R - a b^T fused with the row dots (against trow) and column sums (against wc) of the new R
     static void rank1(rri_ctx* c, void* R, const double* a, const double* b, const double* trow, const double* wc) {
         TimedScope ts(c, 3);
-        if (g_pass_unroll == 2) pass_u<true, true, true, 2>(c, R, trow, wc, a, b);
-        else pass_u<true, true, true, 4>(c, R, trow, wc, a, b);
+        pass_cfg<true, true, true>(c, R, trow, wc, a, b);
     }
     static size_t resid_shmem(const rri_ctx* c) {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
@@ -542,7 +552,9 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->n = n; c->d = d; c->k = k; c->dtype = dtype; c->weighted = weighted; c->device = device;
     c->es = dtype == RRI_F32 ? 4 : 8;
     c->VN = (int)(16 / c->es);
-    c->PW = 64 * c->VN * 4;
+    if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) g_pass_unroll = v; }
+    if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
+    c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
 #define CR(call)                                                                                   \
     do {                                                                                           \
@@ -559,18 +571,16 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
 
     // geometry of the streaming pass
     c->npanels = (int)((c->LD + c->PW - 1) / c->PW);
-    int target = 1024;
+    int target = 4096;
     if (const char* e = getenv("RRI_PASS_WGS")) target = std::max(1, atoi(e));
     int nrb_t = std::max(1, target / c->npanels);
     i64 rpb = (n + nrb_t - 1) / nrb_t;
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
-    if (const char* e = getenv("RRI_PASS_UNROLL")) g_pass_unroll = atoi(e) == 2 ? 2 : 4;
     rpb = std::max<i64>(rpb, rpb_min);
-    rpb = std::min<i64>(round_up(rpb, 16), 2048);
+    rpb = std::min<i64>(round_up(rpb, 16), 1024);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
-    if (const char* e = getenv("RRI_PASS_UNROLL")) g_pass_unroll = atoi(e) == 2 ? 2 : 4;
     c->nwb = (int)((n + 255) / 256);
     c->ntb = (int)((d + 127) / 128);
     c->ldw = n;

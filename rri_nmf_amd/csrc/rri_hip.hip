@@ -26,6 +26,7 @@
 
 #include "rri_hip.h"
 #include "rri_kernels.hpp"
+#include "rri_wrri_kernels.hpp"
 
 using namespace rri;
 
@@ -56,6 +57,7 @@ struct rri_ctx {
     bool own_X = false, own_M = false;
     double *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
     double *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Ttpart = nullptr;
+    double *Y2part = nullptr, *Z2part = nullptr, *dtv = nullptr, *dwv = nullptr, *wold = nullptr, *zeros = nullptr;  // weighted
     i64 ldw = 0;     // row stride of the k-major W (>= n)
     int nsplit = 4;  // column slices of k_tgram
     bool own_red = false;
@@ -208,6 +210,16 @@ struct LaunchX {
     static void rank1(rri_ctx* c, void* R, const double* a, const double* b, const double* trow, const double* wc) {
         TimedScope ts(c, 3);
         pass_cfg<true, true, true>(c, R, trow, wc, a, b);
+    }
+    template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
+    static void wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
+                      const double* a2, const double* b2) {
+        TimedScope ts(c, 3);
+        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, 4>), dim3(c->npanels * c->nrb), dim3(256),
+                           11 * (size_t)c->rpb * sizeof(double), c->stream, (SX*)c->E, (const SX*)c->M, c->LD,
+                           c->ldm, (int)c->n, ncols, trow, wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part,
+                           c->LD, c->rpb, c->npanels, (const DevState*)c->st);
     }
     static size_t resid_shmem(const rri_ctx* c) {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
@@ -461,8 +473,82 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     c->resid_valid = false;
 }
 
+// ---- weighted flavour (rri_wrri_kernels.hpp) ---------------------------------------------------------
+// carry := Zpart / Z2part hold the column sums (a, nw) of topic `carry_topic` over the CURRENT E.
+void w_refresh(rri_ctx* c) {
+    DISPATCH(c, L::resid(c, true, true, nullptr, nullptr));   // E = M .* (X - W T)
+    c->resid_valid = true;
+    c->carry_valid = false;
+}
+
+void w_reduce(rri_ctx* c) {
+    const int nb = (int)((c->LD + 31) / 32);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
+                       (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Z2part, c->LD, c->nrb,
+                       (const double*)nullptr, 0, c->k, c->red + c->LD, (const DevState*)c->st);
+}
+
+void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
+    const double* wt_t = c->W + (i64)t * c->ldw;
+    if (!c->carry_valid || c->carry_topic != t)
+        DISPATCH(c, (L::template wpass<false, true, false, false>(c, nullptr, wt_t, c->zeros, c->zeros, nullptr, nullptr)));
+    {
+        TimedScope ts(c, 2);
+        w_reduce(c);
+        hipLaunchKernelGGL(k_wtrow, dim3(c->ntb), dim3(128), 0, c->stream, (const double*)c->T, c->LD, (int)c->d, t,
+                           (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, kparams(c),
+                           (const DevState*)c->st);
+        const int scale_w = (c->prm.fix_W && no_regs(c)) ? 1 : 0;
+        hipLaunchKernelGGL(k_wtrow_final, dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t, c->xraw,
+                           (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, c->dtv, scale_w, sweep,
+                           kparams(c), c->st);
+    }
+    c->carry_valid = false;
+    if (c->prm.fix_W) {   // no W half follows: fold dt into E now, then rescale the kept column (nmf.py:450-452)
+        DISPATCH(c, (L::template wpass<false, false, false, true>(c, nullptr, nullptr, wt_t, c->dtv, nullptr, nullptr)));
+        if (no_regs(c)) LK::scale_wcol(c, t);
+    }
+}
+
+void enqueue_wW_half(rri_ctx* c, int sweep, int t) {
+    const int k = c->k;
+    const int tn = (t + 1) % k;
+    const double* trow = c->T + (i64)t * c->LD;
+    const double* b1 = c->prm.fix_T ? c->zeros : c->dtv;   // pending T-row correction (none when T is fixed)
+    DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->W + (i64)t * c->ldw, b1, nullptr, nullptr)));
+    {
+        TimedScope ts(c, 1);
+        hipLaunchKernelGGL(k_wwcol, dim3(c->nwb), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, k, t,
+                           (const double*)c->Ypart, (const double*)c->Y2part, c->npanels, c->wold, c->dwv, c->Gpart,
+                           kparams(c), (const DevState*)c->st);
+    }
+    const bool carry_next = (k > 1) && !c->prm.fix_T;
+    const double* wn = c->W + (i64)tn * c->ldw;
+    if (carry_next) DISPATCH(c, (L::template wpass<false, true, true, true>(c, nullptr, wn, c->wold, b1, c->dwv, trow)));
+    else DISPATCH(c, (L::template wpass<false, false, true, true>(c, nullptr, nullptr, c->wold, b1, c->dwv, trow)));
+    int ns = sweep, np = t + 1;
+    if (np == k) { np = 0; ns = sweep + 1; }
+    hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb, k, t, ns, np,
+                       kparams(c), c->st);
+    c->carry_valid = carry_next;
+    c->carry_topic = tn;
+}
+
 void enqueue_from(rri_ctx* c, Cursor cur) {
     const int k = c->k;
+    if (c->weighted) {
+        for (int s = cur.sweep; s < c->run_total; ++s) {
+            const int t0 = (s == cur.sweep) ? cur.topic : 0;
+            for (int t = t0; t < k; ++t) {
+                const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
+                if (!c->resid_valid || (t == 0 && ph == 0)) w_refresh(c);   // once per sweep (and after resets)
+                if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, s, t);
+                if (!c->prm.fix_W) enqueue_wW_half(c, s, t);
+            }
+        }
+        return;
+    }
     for (int s = cur.sweep; s < c->run_total; ++s) {
         const int t0 = (s == cur.sweep) ? cur.topic : 0;
         for (int t = t0; t < k; ++t) {
@@ -571,23 +657,24 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
 
     // geometry of the streaming pass
     c->npanels = (int)((c->LD + c->PW - 1) / c->PW);
-    int target = 4096;
+    int target = 2048;
     if (const char* e = getenv("RRI_PASS_WGS")) target = std::max(1, atoi(e));
     int nrb_t = std::max(1, target / c->npanels);
     i64 rpb = (n + nrb_t - 1) / nrb_t;
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
     rpb = std::max<i64>(rpb, rpb_min);
-    rpb = std::min<i64>(round_up(rpb, 16), 1024);
+    rpb = std::min<i64>(round_up(rpb, 16), weighted ? 512 : 1024);   // LDS: 6 (11 weighted) doubles per row
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
     c->nwb = (int)((n + 255) / 256);
     c->ntb = (int)((d + 127) / 128);
     c->ldw = n;
     c->nsplit = (int)std::max<i64>(1, std::min<i64>(8, d / 2048));
-    c->red_elems = round_up(c->LD + k + 2, 4);
+    c->red_elems = round_up(std::max<i64>(c->LD + k + 2, weighted ? 2 * c->LD : 0), 4);
 
     const size_t f8 = sizeof(double);
+    const size_t es_x = c->es;
     CR(hipMalloc((void**)&c->W, (size_t)k * c->ldw * f8));
     CR(hipMalloc((void**)&c->T, (size_t)k * c->LD * f8));
     CR(hipMemsetAsync(c->T, 0, (size_t)k * c->LD * f8, c->stream));
@@ -604,6 +691,18 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
     CR(hipMalloc((void**)&c->dtmp, 16 * sizeof(double)));
     CR(hipMalloc((void**)&c->itmp, 16 * sizeof(i64)));
+    if (weighted) {
+        const i64 zn = std::max<i64>(c->LD, n);
+        CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+        CR(hipMalloc((void**)&c->Y2part, (size_t)c->npanels * n * f8));
+        CR(hipMalloc((void**)&c->Z2part, (size_t)c->nrb * c->LD * f8));
+        CR(hipMalloc((void**)&c->dtv, (size_t)c->LD * f8));
+        CR(hipMalloc((void**)&c->dwv, (size_t)n * f8));
+        CR(hipMalloc((void**)&c->wold, (size_t)n * f8));
+        CR(hipMalloc((void**)&c->zeros, (size_t)zn * f8));
+        CR(hipMemsetAsync(c->zeros, 0, (size_t)zn * f8, c->stream));
+        CR(hipMemsetAsync(c->dtv, 0, (size_t)c->LD * f8, c->stream));
+    }
     CR(hipMalloc((void**)&c->st, sizeof(DevState)));
     CR(hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream));
     // opt in to large dynamic LDS where a kernel needs it
@@ -623,7 +722,8 @@ rri_status rri_destroy(rri_ctx* c) {
     if (c->own_M) (void)hipFree(c->M);
     void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
-                    (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st};
+                    (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
+                    (void*)c->Z2part, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -749,7 +849,6 @@ rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
     CHECK_CTX(c);
     rri_status r = ready(c);
     if (r != RRI_OK) return r;
-    if (c->weighted) return fail(c, RRI_ERR_UNSUPPORTED, "use the weighted sweep entry (rri_sweep on a weighted handle is routed in rri_wrri.hpp)");
     if (c->paused) return fail(c, RRI_ERR_INVALID, "a paused run is pending: resolve the event and call rri_resume");
     if (n_sweeps < 0) return fail(c, RRI_ERR_INVALID, "n_sweeps < 0");
     c->run_total = n_sweeps;

@@ -250,12 +250,24 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
         for (int q = 0; q < npanels; ++q) y += Ypart[(i64)q * n + i];
     const double wn = (CARRY && valid) ? Wt[(i64)tn * ldw + i] : 0.0;
     double dotv = 0.0;
-    for (int l = 0; l < k; ++l) {
-        const double wl = (valid && !(UPDATE && l == t)) ? Wt[(i64)l * ldw + i] : 0.0;
-        if (UPDATE) dotv = fma(wl, tts[l], dotv);
-        if (CARRY) {
-            const double g = wave_sum<double>(wn * wl);
-            if (lane == 0) gsh[wave * (k + 2) + l] = g;
+    constexpr int CH = 8;   // loads of 8 columns of W are issued together, then consumed
+    for (int l0 = 0; l0 < k; l0 += CH) {
+        double wl[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int l = l0 + q;
+            wl[q] = (l < k && valid && !(UPDATE && l == t)) ? Wt[(i64)l * ldw + i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int l = l0 + q;
+            if (l < k) {   // wave-uniform
+                if (UPDATE) dotv = fma(wl[q], tts[l], dotv);
+                if (CARRY) {
+                    const double g = wave_sum<double>(wn * wl[q]);
+                    if (lane == 0) gsh[wave * (k + 2) + l] = g;
+                }
+            }
         }
     }
     double wnew = 0.0;
@@ -294,7 +306,8 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ Zpar
     if (st->halt) return;
     __shared__ double sh[32 * 33];
     const int tid = threadIdx.x;
-    if (blockIdx.x + 1 < gridDim.x) {
+    // Gpart == NULL: column blocks only (the grid then has no Gram block)
+    if (Gpart == nullptr || blockIdx.x + 1 < gridDim.x) {
         const int c = tid & 31, g = tid >> 5;
         const i64 j = (i64)blockIdx.x * 32 + c;
         double a = 0.0;

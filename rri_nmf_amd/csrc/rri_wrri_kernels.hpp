@@ -1,0 +1,277 @@
+// rri_wrri_kernels.hpp -- elementwise-weighted RRI (the reference's W_mat path, "Algorithm 10 / WRRI":
+// nmf.py:687-701 T side, :735-746 W side; qf_min's vector-c branch optimization.py:75-87).
+//
+// The reference rebuilds Rt = W_mat .* (X - W_{-t} T) with a full GEMM twice per topic.  Here the masked
+// residual E = M .* (X - W T) lives in HBM and is corrected by rank-one terms:
+//     numer_T[j] = sum_i w_i M_ij (X - W_{-t}T)_ij = a_j + t_j nw_j ,  a = w^T E ,  nw = (w^2)^T M
+//     numer_W[i] = b_i + w_i nt_i ,  b = E' t' ,  nt = M (t'^2) ,  E' = E - M .* (w dt^T)
+//     E''        = E' - M .* (dw t'^T)
+// Per topic step two passes over (E, M):
+//   pass B  reads E, M; applies the pending dt correction on the fly; row products b, nt      (no write)
+//   pass C  reads E, M; applies both corrections; writes E; column sums a, nw of the NEXT topic
+// = 5 n d s bytes per topic step (4 n d s + 1 for the rewrite).  E is refreshed from X, W, T
+// (k_resid) once per sweep, so storage rounding of E never accumulates over more than k updates.
+#pragma once
+#include "rri_kernels.hpp"
+
+namespace rri {
+
+// Same block geometry as k_pass: 4 waves = 4 adjacent 1 KiB-wide panels x one row block.
+//   e' = e - m (a1_i b1_j + [UPD2] a2_i b2_j)      (a1,a2: per row, from LDS; b1,b2: per column, registers)
+//   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , Z2part = sum_i w_i^2 m
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U>
+__global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm, int n,
+                                               int ncols,
+                                               const double* __restrict__ trow, const double* __restrict__ wcol,
+                                               const double* __restrict__ a1v, const double* __restrict__ b1v,
+                                               const double* __restrict__ a2v, const double* __restrict__ b2v,
+                                               double* __restrict__ Ypart, double* __restrict__ Y2part,
+                                               double* __restrict__ Zpart, double* __restrict__ Z2part, i64 ldz,
+                                               int rpb, int npg, const DevState* __restrict__ st) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;
+    constexpr int PW = 64 * VN;
+    if (st->halt) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ysh = reinterpret_cast<double*>(smem);   // [4][rpb]
+    double* y2sh = ysh + 4 * rpb;                    // [4][rpb]
+    double* wsh = y2sh + 4 * rpb;                    // [rpb]
+    double* a1sh = wsh + rpb;                        // [rpb]
+    double* a2sh = a1sh + rpb;                       // [rpb]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const int row0 = rb * rpb, row1 = min(n, row0 + rpb);
+    const int col = (pg * 4 + wave) * PW + lane * VN;
+    for (int i = threadIdx.x; i < row1 - row0; i += 256) {
+        if (DO_Z) wsh[i] = wcol[row0 + i];
+        a1sh[i] = a1v[row0 + i];
+        if (UPD2) a2sh[i] = a2v[row0 + i];
+    }
+    __syncthreads();
+    const bool ok = col < ncols;
+    const bool wave_has_cols = (pg * 4 + wave) * PW < ncols;
+    double tv[VN], tsq[VN], b1[VN], b2[VN], zacc[VN], z2acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+        zacc[e] = z2acc[e] = 0.0;
+        tv[e] = (DO_Y && ok) ? trow[col + e] : 0.0;
+        tsq[e] = tv[e] * tv[e];
+        b1[e] = ok ? b1v[col + e] : 0.0;
+        b2[e] = (UPD2 && ok) ? b2v[col + e] : 0.0;
+    }
+    if (wave_has_cols) {
+        for (int r = row0; r < row1; r += U) {
+            V x[U], mk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + u;
+                x[u] = XV::zero();
+                mk[u] = XV::zero();
+                if (rr < row1 && ok) {
+                    x[u] = *reinterpret_cast<const V*>(E + (i64)rr * ldx + col);
+                    mk[u] = stream_load<true>(reinterpret_cast<const V*>(M + (i64)rr * ldm + col));
+                }
+            }
+            double ys[U], y2s[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + u;
+                double wv = 0.0, c1 = 0.0, c2 = 0.0;
+                if (rr < row1) {
+                    if (DO_Z) wv = wsh[rr - row0];
+                    c1 = a1sh[rr - row0];
+                    if (UPD2) c2 = a2sh[rr - row0];
+                }
+                double xe[VN], me[VN];
+                XV::unpack(x[u], xe);
+                XV::unpack(mk[u], me);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    double corr = c1 * b1[e];
+                    if (UPD2) corr = fma(c2, b2[e], corr);
+                    xe[e] = fma(-me[e], corr, xe[e]);
+                }
+                if constexpr (WRITE) {
+                    const V rounded = XV::pack(xe);
+                    if (rr < row1 && ok) *reinterpret_cast<V*>(E + (i64)rr * ldx + col) = rounded;
+                    if constexpr (sizeof(SX) == 4) XV::unpack(rounded, xe);
+                }
+                double yp = 0.0, y2p = 0.0;
+                const double wv2 = wv * wv;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    if (DO_Y) { yp = fma(xe[e], tv[e], yp); y2p = fma(me[e], tsq[e], y2p); }
+                    if (DO_Z) { zacc[e] = fma(wv, xe[e], zacc[e]); z2acc[e] = fma(wv2, me[e], z2acc[e]); }
+                }
+                if (DO_Y) { ys[u] = wave_sum<double>(yp); y2s[u] = wave_sum<double>(y2p); }
+            }
+            if (DO_Y) {
+                double yv = ys[0], y2v = y2s[0];
+#pragma unroll
+                for (int u = 1; u < U; ++u)
+                    if (lane == u) { yv = ys[u]; y2v = y2s[u]; }
+                const int rr = r + lane;
+                if (lane < U && rr < row1) { ysh[wave * rpb + rr - row0] = yv; y2sh[wave * rpb + rr - row0] = y2v; }
+            }
+        }
+        if (DO_Z && ok) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                Zpart[(i64)rb * ldz + col + e] = zacc[e];
+                Z2part[(i64)rb * ldz + col + e] = z2acc[e];
+            }
+        }
+    } else if (DO_Y) {
+        for (int i = lane; i < row1 - row0; i += 64) { ysh[wave * rpb + i] = 0.0; y2sh[wave * rpb + i] = 0.0; }
+    }
+    if (DO_Y) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < row1 - row0; i += 256) {
+            Ypart[(i64)pg * n + row0 + i] = (ysh[i] + ysh[rpb + i]) + (ysh[2 * rpb + i] + ysh[3 * rpb + i]);
+            Y2part[(i64)pg * n + row0 + i] = (y2sh[i] + y2sh[rpb + i]) + (y2sh[2 * rpb + i] + y2sh[3 * rpb + i]);
+        }
+    }
+}
+
+// T row, vector-c qf_min (optimization.py:75-87), before the optional rescale.  red = [a | nw] (2 x ldz).
+// flags[b] = 1 when the block saw a negative denominator (-> "unbounded" unless s or ub is given).
+__global__ __launch_bounds__(128) void k_wtrow(const double* __restrict__ T, i64 ldt, int d, int t,
+                                               const double* __restrict__ red, i64 ldz, double* __restrict__ xraw,
+                                               double* __restrict__ tpart, i64* __restrict__ flags, KParams p,
+                                               const DevState* __restrict__ st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const int tid = threadIdx.x;
+    const i64 j = (i64)blockIdx.x * 128 + tid;
+    double x = 0.0, neg = 0.0;
+    if (j < d) {
+        const double a = red[j], nw = red[ldz + j], tj = T[(i64)t * ldt + j];
+        const double numer = fma(tj, nw, a) - p.reg_t_l1;      // w^T Rt - reg_t_l1 (nmf.py:437)
+        const double c = nw + p.reg_t_l2;                       // nmf.py:438
+        if (c < 0.0) neg = 1.0;
+        if (c > 0.0) x = fmax(numer, 0.0) / (c + p.eps);
+        if (p.has_trs) x = fmin(x, p.t_row_sum);                // ub = t_row_sum (min(ub, s) when s is given)
+        xraw[j] = x;
+    }
+    const double s = block_sum(x, scratch);
+    const double ng = block_sum(neg, scratch);
+    if (tid == 0) { tpart[blockIdx.x] = s; flags[blockIdx.x] = ng > 0.0 ? 1 : 0; }
+}
+
+// finishes the weighted T row: unbounded check, rescale to sum s (optimization.py:85-87), the row checks of
+// _project_and_check_reset_t, T[t,:] and dt = scale_w * t_new - t_old (scale_w = nt1 when fix_W keeps and
+// rescales the column, nmf.py:450-452; 1 otherwise).
+__global__ __launch_bounds__(1024) void k_wtrow_final(double* __restrict__ T, i64 ldt, int d, int t,
+                                                      double* __restrict__ xraw, const double* __restrict__ tpart,
+                                                      const i64* __restrict__ flags, int nblk,
+                                                      double* __restrict__ dt, int scale_w, int sweep, KParams p,
+                                                      DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const int tid = threadIdx.x;
+    double ps = 0.0, pf = 0.0;
+    for (int b = tid; b < nblk; b += blockDim.x) { ps += tpart[b]; pf += (double)flags[b]; }
+    const double nx = block_sum(ps, scratch);
+    const double anyneg = block_sum(pf, scratch);
+    const bool project = p.project_T && p.has_trs;
+    if (anyneg > 0.0 && !project && !p.has_trs) {     // any(c<0) and s is None and ub is None
+        if (tid == 0) { st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
+        return;
+    }
+    double sumT = nx;
+    if (project) {
+        const double f = p.t_row_sum / nx;            // x = s * x / x.sum()
+        for (int j = tid; j < d; j += blockDim.x) xraw[j] = p.t_row_sum * xraw[j] / nx;
+        (void)f;
+        __syncthreads();
+        double s2 = 0.0;
+        for (int j = tid; j < d; j += blockDim.x) s2 += xraw[j];
+        sumT = block_sum(s2, scratch);
+    }
+    bool event = false;
+    if (sumT > 1e-10 || p.reset_method == RESET_NONE) {
+        if (p.has_trs && p.t_row_sum != 0.0 && p.project_T && fabs(sumT - p.t_row_sum) > 1e-15) {
+            int it2 = 0;
+            const double th = simplex_theta(xraw, d, p.t_row_sum, scratch, &it2);
+            for (int j = tid; j < d; j += blockDim.x) xraw[j] = fmax(xraw[j] - th, 0.0);
+        }
+    } else if (p.resets_left > 0) {
+        event = true;
+    }
+    __syncthreads();
+    const double sw = scale_w ? nx : 1.0;
+    for (int j = tid; j < d; j += blockDim.x) {
+        const double told = T[(i64)t * ldt + j], tnew = xraw[j];
+        dt[j] = sw * tnew - told;
+        T[(i64)t * ldt + j] = tnew;
+    }
+    if (tid == 0) {
+        st->nt1 = nx;
+        st->sumT = sumT;
+        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
+    }
+}
+
+// W column, vector-c qf_min: numer_i = b_i + w_i nt_i - reg_w_l1, c_i = nt_i + reg_w_l2 (nmf.py:464-469).
+// Writes W[:,t], wold = previous column, dw = new - old; Gpart[b][k+1] = sum of the new column,
+// Gpart[b][k] = 1 when a negative denominator was seen.
+__global__ __launch_bounds__(256) void k_wwcol(double* __restrict__ Wt, i64 ldw, int n, int k, int t,
+                                               const double* __restrict__ Ypart, const double* __restrict__ Y2part,
+                                               int npg, double* __restrict__ wold, double* __restrict__ dw,
+                                               double* __restrict__ Gpart, KParams p, const DevState* __restrict__ st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    double wnew = 0.0, neg = 0.0;
+    if (i < n) {
+        double b = 0.0, nt = 0.0;
+        for (int q = 0; q < npg; ++q) { b += Ypart[(i64)q * n + i]; nt += Y2part[(i64)q * n + i]; }
+        const double w0 = Wt[(i64)t * ldw + i];
+        const double numer = fma(w0, nt, b) - p.reg_w_l1;
+        const double c = nt + p.reg_w_l2;
+        if (c < 0.0) neg = 1.0;
+        if (c > 0.0) wnew = fmax(numer, 0.0) / (c + p.eps);
+        if (p.has_wrs) wnew = fmin(wnew, p.w_row_sum);
+        Wt[(i64)t * ldw + i] = wnew;
+        wold[i] = w0;
+        dw[i] = wnew - w0;
+    }
+    const double sw = block_sum(wnew, scratch);
+    const double ng = block_sum(neg, scratch);
+    if (threadIdx.x == 0) {
+        double* gp = Gpart + (i64)blockIdx.x * (k + 2);
+        gp[k] = ng;
+        gp[k + 1] = sw;
+    }
+}
+
+// column check for the weighted flavour: unbounded (negative denominator without ub) first, then the
+// reset / assert logic of k_check_wcol
+__global__ __launch_bounds__(256) void k_wcheck_wcol(const double* __restrict__ Gpart, int nwb, int k, int tprev,
+                                                     int sweep, int pos, KParams p, DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    double a = 0.0, f = 0.0;
+    for (int b = threadIdx.x; b < nwb; b += blockDim.x) {
+        a += Gpart[(i64)b * (k + 2) + k + 1];
+        f += Gpart[(i64)b * (k + 2) + k];
+    }
+    a = block_sum(a, scratch);
+    f = block_sum(f, scratch);
+    if (threadIdx.x == 0) {
+        if (f > 0.0 && !p.has_wrs) {
+            st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+            return;
+        }
+        const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(a > 0.0);
+        if (ev || err) {
+            st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+        }
+    }
+}
+
+}  // namespace rri

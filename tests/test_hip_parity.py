@@ -263,3 +263,84 @@ def test_rank1_update_and_copy_bench_run():
         e.sweep(2)
         cnt, ms = e.timing_read(0)
         assert cnt == 2 * 4 + 1 and ms > 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# elementwise-weighted flavour (WRRI; nmf.py:687-701, 735-746)
+# ---------------------------------------------------------------------------------------------------------
+def run_weighted(X, M, W0, T0, sweeps, dtype, **params):
+    n, d = X.shape
+    k = W0.shape[1]
+    with engine(n, d, k, dtype=dtype, weighted=True) as e:
+        e.upload_X(X)
+        e.upload_mask(M)
+        e.set_W(np.maximum(W0, 0))
+        e.set_T(np.maximum(T0, 0))
+        e.set_params(**params)
+        e.sweep(sweeps)
+        if params.get('w_row_sum') is not None and not params.get('fix_W'):
+            e.project_W_rows(params['w_row_sum'])      # nmf()'s final projection (nmf.py:519-529)
+        return e.get_W(), e.get_T(), e.objective()
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_weighted_flavour_synthetic(tag, dtype):
+    """well-conditioned 30 % mask: W and T themselves are comparable"""
+    g = load_golden('g5_plain_' + tag)
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=0, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    M = (np.random.RandomState(2).rand(n, d) < 0.3).astype(np.float64)
+    Xm = stored(M * X, dtype)
+    flags = dict(t_row_sum=1.0, reset_topic_method=None)
+    W, T, obj = run_weighted(Xm, M, W0, T0, 4, dtype, **flags)
+    ref = run_oracle(Xm, W0, T0, 4, W_mat=M, compute_obj_each_iter=True, **flags)
+    # float64 residual: summation-order only.  fp32 residual: E is rounded to fp32 at every store (and
+    # refreshed each sweep), so the bar is BASELINE's 1e-4
+    tol = 5e-9 if dtype == np.float64 else 1e-4
+    assert relfro(W, ref['W']) < tol and relfro(T, ref['T']) < tol, (relfro(W, ref['W']), relfro(T, ref['T']))
+    assert abs(obj - ref['obj_history'][-1]) < (1e-9 if dtype == np.float64 else 1e-5) * abs(obj)
+    if dtype == np.float64:
+        assert relfro(W, g['wr_W_s4']) < tol and relfro(T, g['wr_T_s4']) < tol
+    # l1 penalties, general (non 0/1) weights, fixed halves
+    Mw = M * (0.5 + np.random.RandomState(3).rand(n, d))
+    for kw in (dict(reg_w_l1=0.05, reg_t_l1=0.02), dict(fix_T=True), dict(fix_W=True),
+               dict(w_row_sum=2.0, reg_w_l2=0.1, reg_t_l2=0.2)):
+        W, T, _ = run_weighted(Xm, Mw, W0, T0, 3, dtype, **dict(flags, **kw))
+        ref = run_oracle(Xm, W0, T0, 3, W_mat=Mw, **dict(flags, **kw))
+        assert relfro(W, ref['W']) < tol and relfro(T, ref['T']) < tol, (kw, relfro(W, ref['W']), relfro(T, ref['T']))
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_weighted_recsys_fixture(dtype):
+    """the reference's own WRRI test settings (tests/test_nmf.py:57-78) on its recsys fixture.  Some T entries
+    there have denominators ~1e-27: W, T agree only in the early sweeps, the masked
+    reconstruction M.(WT) and the objective agree throughout."""
+    g = load_golden('g4_wrri')
+    X = g['X'].astype(np.float64)
+    M = np.zeros(X.shape)
+    M[X.nonzero()] = 1.0
+    cases = [{}, {'reg_w_l1': 0.1, 'reg_t_l1': 0.1}, {'reg_w_l1': 0.1}, {'reg_t_l1': 0.1}]
+    for ci, c in enumerate(cases):
+        flags = dict(c, reset_topic_method=None, t_row_sum=1.0)
+        Wr, Tr = g['c%d_W_s1' % ci], g['c%d_T_s1' % ci]
+        W, T, _ = run_weighted(X, M, g['W0'], g['T0'], 1, dtype, **flags)
+        if dtype == np.float64:       # first sweep: every entry is well determined
+            assert relfro(W, Wr) < 1e-9 and relfro(T, Tr) < 1e-9, (relfro(W, Wr), relfro(T, Tr))
+        assert relfro(M * (W @ T), M * (Wr @ Tr)) < (1e-9 if dtype == np.float64 else 1e-5)
+        tol_rec = 1e-6 if dtype == np.float64 else 1e-4
+        for S, Wr, Tr in ((2, g['c%d_W_s2' % ci], g['c%d_T_s2' % ci]), (6, g['c%d_W_s6' % ci], g['c%d_T_s6' % ci]),
+                          (15, g['c%d_W' % ci], g['c%d_T' % ci])):
+            W, T, obj = run_weighted(X, M, g['W0'], g['T0'], S, dtype, **flags)
+            assert relfro(M * (W @ T), M * (Wr @ Tr)) < tol_rec, (S, relfro(M * (W @ T), M * (Wr @ Tr)))
+        assert abs(obj - g['c%d_obj' % ci][-1]) < tol_rec * abs(obj)
+        # monotone objective, as the reference's test asserts
+        objs = []
+        with engine(X.shape[0], X.shape[1], 7, dtype=dtype, weighted=True) as e:
+            e.upload_X(X); e.upload_mask(M); e.set_W(g['W0']); e.set_T(g['T0']); e.set_params(**flags)
+            for _ in range(15):
+                e.sweep(1)
+                objs.append(e.objective())
+        assert np.all(np.diff(objs) <= 1e-9 * abs(objs[0]))
+        assert np.allclose(objs, g['c%d_obj' % ci], rtol=(1e-6 if dtype == np.float64 else 1e-4))

@@ -188,3 +188,39 @@ def test_sharded_stepping_single_rank_matches_sweep():
         dist.destroy_process_group()
     assert np.array_equal(Wa, Wb) and np.array_equal(Ta, Tb)
     assert abs(obja - objb) <= 1e-12 * abs(obja)
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+def test_convergence_rs_setting(ci):
+    """tests/test_nmf.py:57-78: weighted NMF on the recsys fixture, objective non-increasing"""
+    nmf_mod, _ = api()
+    g = load_golden('g4_wrri')
+    X = g['X']
+    Wm = np.zeros(X.shape)
+    Wm[X.nonzero()] = 1.0
+    cases = [{}, {'reg_w_l1': 0.1, 'reg_t_l1': 0.1}, {'reg_w_l1': 0.1}, {'reg_t_l1': 0.1}]
+    p = dict(cases[ci], max_iter=15, random_state=0, W_mat=Wm, compute_obj_each_iter=True, reset_topic_method=None,
+             early_stop=False, k=7, project_T_each_iter=False, t_row_sum=1.0, project_W_each_iter=False,
+             w_row_sum=None)
+    soln = nmf_mod.nmf(X, **p)
+    oh = np.array(soln['obj_history'])
+    assert np.all(np.diff(oh) <= 1e-9 * abs(oh[0]))
+    assert len(oh) == len(g['c%d_obj' % ci]) and np.allclose(oh, g['c%d_obj' % ci], rtol=1e-6)
+
+
+def test_convergence_RS_Estimator():
+    """tests/test_nmf.py:81-88 plus the reference's numbers for both early-stopping settings"""
+    _, si = api()
+    g = load_golden('g4_wrri')
+    X = g['X']
+    n, d = X.shape
+    E = si.NMF_RS_Estimator(n, d, 5, random_state=0, max_iter=20).fit_from_Xtr(X)
+    score = E.score(X)
+    assert score < 1.0
+    assert abs(score - float(g['rs_es_score'])) < 1e-5 and abs(E.score(g['Xte']) - float(g['rs_es_score_te'])) < 1e-5
+    assert len(E.nmf_outputs['obj_history']) == len(g['rs_es_obj'])
+    E2 = si.NMF_RS_Estimator(n, d, 5, random_state=0, max_iter=20, use_validation_early_stopping=False)
+    E2 = E2.fit_from_Xtr(X)
+    assert abs(E2.score(X) - float(g['rs_noes_score'])) < 1e-4
+    Wnew = E2.transform(g['Xte'].astype(np.float64))
+    assert Wnew.shape == (n, 5) and Wnew.min() >= 0

@@ -14,6 +14,8 @@ Workloads (BASELINE.json configs):
                   i.e. N * (global sweeps/s): it equals plain sweeps/s at N = 1.
     c2            10000 x 1000, k=20 (X is Infinity-Cache resident: latency-, not HBM-bound).
     c4            1000000 x 10000, k=50 split by rows over the N ranks (STRONG scaling).
+    c5            WRRI: c3's shape with a dense fp32 5 %-observed 0/1 mask, recommender flags (T clipped to
+                  [0,1], no resets); single GPU.  Algorithmic bytes 5*n*d*4 per topic step.
 
 Prints ONE JSON line on rank 0 (contract in the task description) including
     roofline     : the dominant kernel (the fused X pass) -- algorithmic bytes n_local*d*4 per launch
@@ -37,6 +39,8 @@ CONFIGS = {
     'c2': dict(n=10000, d=1000, k=20, scaling='weak', name='synthetic dense fp32 X 10000x1000 k=20'),
     'c3': dict(n=100000, d=10000, k=50, scaling='weak', name='synthetic dense fp32 X 100000x10000 k=50'),
     'c4': dict(n=1000000, d=10000, k=50, scaling='strong', name='synthetic dense fp32 X 1000000x10000 k=50'),
+    'c5': dict(n=100000, d=10000, k=50, scaling='weak', weighted=True,
+               name='elementwise-weighted WRRI (Algorithm 10), dense fp32 X 100000x10000 k=50, 5% observed 0/1 mask'),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
@@ -47,6 +51,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--cpu-sweeps', type=int, default=2)
     ap.add_argument('--cpu-rows', type=int, default=10000, help='rows of X in the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
@@ -151,11 +156,24 @@ def main():
     W0 = (a * torch.rand(n_local, k, device=device, generator=gw, dtype=torch.float64)).cpu().numpy()
     torch.cuda.synchronize()
 
-    eng, red, stream = make_device_shard(n_local, d, k, dtype=np.float32, device_index=local_rank)
+    weighted = bool(cfg.get('weighted'))
+    if weighted and world > 1:
+        raise SystemExit('the weighted workload is single-GPU')
+    Mask = None
+    if weighted:
+        gm = torch.Generator(device=device)
+        gm.manual_seed(2)
+        Mask = (torch.rand(n_local, d, device=device, generator=gm) < 0.05).to(torch.float32)
+        X.mul_(Mask)
+        torch.cuda.synchronize()
+    eng, red, stream = make_device_shard(n_local, d, k, dtype=np.float32, device_index=local_rank, weighted=weighted)
     eng.bind_X_device(X.data_ptr(), X.stride(0))
+    if weighted:
+        eng.bind_mask_device(Mask.data_ptr(), Mask.stride(0))
     eng.set_W(W0)
     eng.set_T(T0)
-    eng.set_params()     # plain RRI: no constraints, default reset policy
+    flags = dict(t_row_sum=1.0, reset_topic_method=None) if weighted else {}
+    eng.set_params(**flags)   # plain RRI: no constraints, default resets; WRRI: the RS-fit flags
     drv = ShardedRRI(eng, red, k, stream=stream) if world > 1 else None
 
     def run(steps):
@@ -184,11 +202,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
 
-    launches, pass_ms = eng.timing_read(0)
+    launches, pass_ms = eng.timing_read(3 if weighted else 0)
     _, wcol_ms = eng.timing_read(1)
     _, trow_ms = eng.timing_read(2)
     pass_avg_ms = pass_ms / max(launches, 1)
-    bytes_per_launch = float(n_local) * d * 4
+    # plain: one fused pass reads X once.  weighted: two passes per topic step over (E, M) move 2 + 3 = 5 arrays
+    bytes_per_launch = float(n_local) * d * 4 * (2.5 if weighted else 1.0)
     achieved = bytes_per_launch / (pass_avg_ms * 1e-3) / 1e9 if launches else 0.0
     sweeps_per_s = args.steps / elapsed
     shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
@@ -202,22 +221,47 @@ def main():
         'config': {'workload': cfg['name'] + (' per GPU (row shard), %d x %d global' % (n_global, d)
                                               if world > 1 and cfg['scaling'] == 'weak' else ''),
                    'n_global': n_global, 'n_per_gpu': n_local, 'd': d, 'k': k,
-                   'x_storage': 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'plain RRI',
+                   'x_storage': 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
                    'parallelism': 'row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step'
                                   % (world, d + k + 2) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                     'kernel': 'k_pass<float,Y,Z> (fused row-dot + column-sum pass over X)',
+                     'kernel': ('k_wpass<float,...> passes B (read E,M) and C (read E,M; write E), averaged' if weighted
+                                else 'k_pass<float,Y,Z> (fused row-dot + column-sum pass over X)'),
                      'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},
         'sweep_level': {'global_sweeps_per_s': sweeps_per_s,
                         'x_passes_per_sweep': launches / float(args.steps) if args.steps else None,
-                        'algorithmic_GBps_2knd': 2.0 * k * n_local * d * 4 * sweeps_per_s / 1e9,
-                        'frac_of_8TBps_2knd': 2.0 * k * n_local * d * 4 * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
+                        'algorithmic_GBps_2knd': (2.0 if not weighted else 4.0) * k * n_local * d * 4 * sweeps_per_s / 1e9,
+                        'frac_of_8TBps_2knd': (2.0 if not weighted else 4.0) * k * n_local * d * 4 * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
                         'kernel_ms_per_sweep': {'pass': pass_ms / args.steps, 'wcol': wcol_ms / args.steps,
                                                 'trow_chain': trow_ms / args.steps}},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and weighted and not args.no_cpu_baseline:
+        rows = min(2000, n_local)
+        Xs, Ms = X[:rows].cpu().numpy().astype(np.float64), Mask[:rows].cpu().numpy().astype(np.float64)
+        from oracle import rri_oracle as orc
+        from threadpoolctl import threadpool_limits
+        thr = int(min(16, os.cpu_count() or 16))
+        with threadpool_limits(limits=thr):
+            t1 = time.perf_counter()
+            ref = orc.nmf(Xs, k, W_in=W0[:rows].copy(), T_in=T0.copy(), W_mat=Ms, max_iter=1, eps_stop=-1, **flags)
+            dt1 = time.perf_counter() - t1
+        out['cpu_baseline'] = dict(value=(1.0 / dt1) * rows / float(n_local), unit='sweeps/s', cores=thr, kind='port',
+                                   sample='first %d of %d rows, 1 sweep (two n*d*k GEMMs per topic step), numpy float64 on %d '
+                                          'threads; sample rate %.4f sweeps/s scaled by %.4g' % (rows, n_local, thr, 1.0 / dt1, rows / float(n_local)))
+        from rri_nmf_amd.engine import RRIEngine
+        with RRIEngine(rows, d, k, dtype=np.float32, weighted=True, device=local_rank) as e2:
+            e2.upload_X(Xs); e2.upload_mask(Ms); e2.set_W(W0[:rows]); e2.set_T(T0); e2.set_params(**flags)
+            e2.sweep(1)
+            Wg, Tg = e2.get_W(), e2.get_T()
+        rec = lambda W_, T_: Ms * (W_ @ T_)
+        out['parity_sample'] = {'sweeps': 1, 'rows': rows,
+                                'relfro_W': float(np.linalg.norm(Wg - ref['W']) / np.linalg.norm(ref['W'])),
+                                'relfro_T': float(np.linalg.norm(Tg - ref['T']) / np.linalg.norm(ref['T'])),
+                                'relfro_masked_WT': float(np.linalg.norm(rec(Wg, Tg) - rec(ref['W'], ref['T'])) / np.linalg.norm(rec(ref['W'], ref['T'])))}
+        out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+    if rank == 0 and world == 1 and not weighted:
         # the explicit rank-one residual update R <- R - a b^T (read + write, fused residual products)
         try:
             r1_ms = eng.bench_rank1_update(5)

@@ -72,14 +72,14 @@ class ShardedRRI(object):
         return base + 0.5 * reg_w_l2 * w2 + 0.5 * reg_t_l2 * t2 + reg_t_l1 * t1 + reg_w_l1 * w1
 
 
-def make_device_shard(n_local, d, k, dtype=np.float32, device_index=0):
+def make_device_shard(n_local, d, k, dtype=np.float32, device_index=0, weighted=False):
     """Engine on a dedicated torch stream of `device_index` with a torch-owned reduce buffer.
     Returns (engine, red tensor, torch stream); pass the stream to ShardedRRI."""
     import torch
     from .engine import RRIEngine
     torch.cuda.set_device(device_index)
     stream = torch.cuda.Stream(device=device_index)   # a real (non-default) HIP stream handle
-    eng = RRIEngine(n_local, d, k, dtype=dtype, device=device_index, stream=stream.cuda_stream)
+    eng = RRIEngine(n_local, d, k, dtype=dtype, weighted=weighted, device=device_index, stream=stream.cuda_stream)
     _, n_elems = eng.reduce_buffer()
     red = torch.zeros(n_elems, dtype=torch.float64, device='cuda:%d' % device_index)
     torch.cuda.synchronize(device_index)

@@ -51,7 +51,7 @@ enum {
     RRI_ERR_NOT_IMPLEMENTED = -6 /* qf_min: c<=0 with s not in {None,1.0} (optimization.py:72-73) */
 };
 
-enum { RRI_F32 = 0, RRI_F64 = 1 };                       /* arithmetic type of the path */
+enum { RRI_F32 = 0, RRI_F64 = 1 };   /* storage type of X, mask, residual in HBM (arithmetic is float64) */
 enum { RRI_RESET_NONE = 0, RRI_RESET_MAX_RESID_DOCUMENT = 1, RRI_RESET_RANDOM = 2 };
 enum { RRI_EVENT_NONE = 0, RRI_EVENT_RESET_T = 1, RRI_EVENT_RESET_W = 2 };
 
@@ -159,6 +159,9 @@ rri_status rri_objective_parts(rri_ctx* ctx, double out[3]);
 /* HIP-event timing of the streaming kernels on the handle's stream.  kernel_id:
  * 0 = fused X pass (row dots + column sums), 1 = W-column update, 2 = T-row update chain,
  * 3 = rank-one residual update (explicit-residual / WRRI flavour). */
+/* on = 0: off; on = N > 0: bracket every N-th launch of each kernel id with an event pair (N = 1: all).
+ * An event record costs a bubble of a few microseconds on the stream, so sample when the timed region is
+ * also the throughput measurement. */
 rri_status rri_timing_enable(rri_ctx* ctx, int32_t on);
 rri_status rri_timing_read(rri_ctx* ctx, int32_t kernel_id, int64_t* launches, double* total_ms);
 rri_status rri_synchronize(rri_ctx* ctx);

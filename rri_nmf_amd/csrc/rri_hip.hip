@@ -12,7 +12,7 @@
 //   Ypart npanels x n      per-column-panel partial row dots of the pass
 //   Zpart nrb x LD         per-row-block partial column sums of the pass
 //   Gpart nwb x (k+2)      per-block partial Gram row / norm / column sum (float64)
-//   red   LD + k + 2       reduced [w^T X | w^T W | ||w||^2 | sum W[:,t-1]]  (all-reduce payload)
+//   red   LD + 8 (k+2)     reduced [w^T X | 8 slice sums of (w^T W, ||w||^2, sum W[:,t-1])]  (all-reduce payload)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -87,8 +87,11 @@ struct rri_ctx {
     rri_event pending{RRI_EVENT_NONE, -1, 0, 0};
 
     bool resid_valid = false;  // masked residual E is in sync with (W,T) (weighted flavour)
+    bool skip_row_finish = false;  // the resumed W half must not re-run the T-row checks (stale partial sums)
+    int nwb256 = 1;
 
-    bool timing = false;
+    int timing = 0;            // 0 off, N > 0: time every N-th launch of each kernel id
+    long timing_seq[4] = {0, 0, 0, 0};
     std::vector<TimedLaunch> timed[4];
     std::vector<hipEvent_t> event_pool;
 
@@ -154,7 +157,9 @@ struct TimedScope {
     int id;
     TimedLaunch tl{nullptr, nullptr};
     bool on;
-    TimedScope(rri_ctx* c_, int id_) : c(c_), id(id_), on(c_->timing && c_->timed[id_].size() < 400000) {
+    TimedScope(rri_ctx* c_, int id_)
+        : c(c_), id(id_),
+          on(c_->timing > 0 && (c_->timing_seq[id_]++ % c_->timing) == 0 && c_->timed[id_].size() < 400000) {
         if (on) {
             tl.a = get_event(c);
             tl.b = get_event(c);
@@ -266,7 +271,7 @@ struct LaunchX {
     } while (0)
 
 struct LK {  // float64-only kernels
-    static size_t wcol_shmem(const rri_ctx* c) { return (size_t)(4 * (c->k + 2) + c->k) * sizeof(double); }
+    static size_t wcol_shmem(const rri_ctx* c) { return (size_t)(2 * c->k + 2 + 256 + 64) * sizeof(double); }
     template <bool UPDATE, bool CARRY>
     static void wcol(rri_ctx* c, int t, int tn, int sweep) {
         TimedScope ts(c, 1);
@@ -275,24 +280,28 @@ struct LK {  // float64-only kernels
                            c->nsplit, c->Gpart, sweep, kparams(c), c->st);
     }
     static void reduce(rri_ctx* c) {
-        const int nb = (int)((c->LD + 31) / 32) + 1;
+        const int nb = (int)((c->LD + 31) / 32) + GRAM_SLICES;
         hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
                            (const double*)c->Gpart, c->nwb, c->k, c->red, (const DevState*)c->st);
     }
-    static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep) {
+    // no simplex projection configured: k_trow_numer stores the row itself and k_tgram finishes the checks
+    static bool light(const rri_ctx* c) { return !(c->prm.project_T_each_iter && c->prm.has_t_row_sum); }
+    static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
         hipLaunchKernelGGL(k_trow_numer, dim3(c->ntb), dim3(128), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, check_prev, tprev, sweep,
                            kparams(c), c->st);
-        hipLaunchKernelGGL(k_trow_final, dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t, c->xraw,
-                           (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep, kparams(c), c->st);
+        if (!light(c) || force_final)
+            hipLaunchKernelGGL(k_trow_final, dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t, c->xraw,
+                               (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep, kparams(c), c->st);
     }
     static void check_prev_only(rri_ctx* c, int tprev, int sweep, int pos) {
         hipLaunchKernelGGL(k_check_red, dim3(1), dim3(64), 0, c->stream, (const double*)c->red, c->LD, c->k, tprev,
                            sweep, pos, kparams(c), c->st);
     }
-    static void tgram(rri_ctx* c, int t) {
+    static void tgram(rri_ctx* c, int t, int finish, int sweep) {
         hipLaunchKernelGGL(k_tgram, dim3(c->k, c->nsplit), dim3(256), 0, c->stream, (const double*)c->T, c->LD,
-                           (int)c->d, c->k, t, c->Ttpart, (const DevState*)c->st);
+                           (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->ntb, finish, sweep,
+                           kparams(c), c->st);
     }
     static void scale_wcol(rri_ctx* c, int t) {
         hipLaunchKernelGGL(k_scale_wcol, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->W,
@@ -303,7 +312,7 @@ struct LK {  // float64-only kernels
                            tprev, sweep, pos, kparams(c), c->st);
     }
     static void proj_rows(rri_ctx* c, double s, const double* svec) {
-        hipLaunchKernelGGL(k_proj_rows, dim3(c->nwb), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, c->k, s,
+        hipLaunchKernelGGL(k_proj_rows, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, c->k, s,
                            svec);
     }
     static void norms(rri_ctx* c, const double* A, i64 rows, i64 cols, i64 ld) {
@@ -432,13 +441,13 @@ void enqueue_prologue(rri_ctx* c, int t, int sweep) {
     c->carry_topic = t;
 }
 
-void enqueue_T_half(rri_ctx* c, int sweep, int t) {
+void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     if (!c->carry_valid || c->carry_topic != t) enqueue_prologue(c, t, sweep);
     {
         TimedScope ts(c, 2);
         LK::reduce(c);
         const int chk = c->pending_wcheck ? 1 : 0;
-        LK::trow(c, t, chk, c->pending_wcheck_topic, sweep);
+        LK::trow(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
         c->pending_wcheck = false;
         if (c->prm.fix_W && no_regs(c)) LK::scale_wcol(c, t);
     }
@@ -452,7 +461,9 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int tn = (t + 1) % k;
     {
         TimedScope ts(c, 2);
-        LK::tgram(c, t);
+        const int finish = (LK::light(c) && !c->skip_row_finish) ? 1 : 0;
+        c->skip_row_finish = false;
+        LK::tgram(c, t, finish, sweep);
     }
     if (carry_next) {
         DISPATCH(c, (L::template pass<true, true>(c, t, tn)));
@@ -519,7 +530,7 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t) {
     DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->W + (i64)t * c->ldw, b1, nullptr, nullptr)));
     {
         TimedScope ts(c, 1);
-        hipLaunchKernelGGL(k_wwcol, dim3(c->nwb), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, k, t,
+        hipLaunchKernelGGL(k_wwcol, dim3(c->nwb256), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, k, t,
                            (const double*)c->Ypart, (const double*)c->Y2part, c->npanels, c->wold, c->dwv, c->Gpart,
                            kparams(c), (const DevState*)c->st);
     }
@@ -529,7 +540,7 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t) {
     else DISPATCH(c, (L::template wpass<false, false, true, true>(c, nullptr, nullptr, c->wold, b1, c->dwv, trow)));
     int ns = sweep, np = t + 1;
     if (np == k) { np = 0; ns = sweep + 1; }
-    hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb, k, t, ns, np,
+    hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, k, t, ns, np,
                        kparams(c), c->st);
     c->carry_valid = carry_next;
     c->carry_topic = tn;
@@ -553,7 +564,7 @@ void enqueue_from(rri_ctx* c, Cursor cur) {
         const int t0 = (s == cur.sweep) ? cur.topic : 0;
         for (int t = t0; t < k; ++t) {
             const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
-            if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, s, t);
+            if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, s, t, c->prm.fix_W != 0);
             if (!c->prm.fix_W) enqueue_W_half(c, s, t);
         }
     }
@@ -667,11 +678,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     rpb = std::min<i64>(round_up(rpb, 16), weighted ? 512 : 1024);   // LDS: 6 (11 weighted) doubles per row
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
-    c->nwb = (int)((n + 255) / 256);
+    c->nwb = (int)((n + 64 * WCOL_TILES - 1) / (64 * WCOL_TILES));   // k_wcol blocks = rows of Gpart
+    c->nwb256 = (int)((n + 255) / 256);
     c->ntb = (int)((d + 127) / 128);
     c->ldw = n;
     c->nsplit = (int)std::max<i64>(1, std::min<i64>(8, d / 2048));
-    c->red_elems = round_up(std::max<i64>(c->LD + k + 2, weighted ? 2 * c->LD : 0), 4);
+    c->red_elems = round_up(std::max<i64>(c->LD + (i64)GRAM_SLICES * (k + 2), weighted ? 2 * c->LD : 0), 4);
 
     const size_t f8 = sizeof(double);
     const size_t es_x = c->es;
@@ -875,6 +887,7 @@ rri_status rri_pending_event(rri_ctx* c, rri_event* ev) {
 }
 
 static void event_resolved(rri_ctx* c) {
+    if (c->pending.kind == RRI_EVENT_RESET_T) c->skip_row_finish = true;
     c->pending.kind = RRI_EVENT_NONE;
     if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
     invalidate(c);
@@ -934,7 +947,7 @@ rri_status rri_update_T_row(rri_ctx* c, int32_t t) {
     c->run_total = 1;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
-    enqueue_T_half(c, 0, t);
+    enqueue_T_half(c, 0, t, true);
     DevState s;
     r = read_state(c, &s);
     if (r != RRI_OK) return r;
@@ -951,6 +964,7 @@ rri_status rri_update_W_col(rri_ctx* c, int32_t t) {
     c->run_total = 1;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
+    c->skip_row_finish = true;   // a lone W half: the T-row checks belong to rri_update_T_row
     enqueue_W_half(c, 0, t);
     if (c->pending_wcheck) {
         LK::check_wcol(c, c->pending_wcheck_topic, 1, 0);
@@ -1146,7 +1160,7 @@ rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     }
     if (t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     const int chk = c->pending_wcheck ? 1 : 0;
-    LK::trow(c, t, chk, c->pending_wcheck_topic, 0);
+    LK::trow(c, t, chk, c->pending_wcheck_topic, 0, false);
     c->pending_wcheck = false;
     c->carry_valid = false;
     enqueue_W_half(c, 0, t);
@@ -1168,7 +1182,8 @@ rri_status rri_poll(rri_ctx* c) {
 // ---- measurement ---------------------------------------------------------------------------------------------
 rri_status rri_timing_enable(rri_ctx* c, int32_t on) {
     CHECK_CTX(c);
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : on;
+    for (int i = 0; i < 4; ++i) c->timing_seq[i] = 0;
     return RRI_OK;
 }
 
@@ -1242,8 +1257,8 @@ rri_status rri_bench_rank1_update(rri_ctx* c, int32_t reps, double* avg_ms) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    const bool tm = c->timing;
-    c->timing = false;
+    const int tm = c->timing;
+    c->timing = 0;
     DISPATCH(c, L::rank1(c, R, a, c->T, c->T, a));
     (void)hipEventRecord(e0, c->stream);
     for (int r = 0; r < reps; ++r) DISPATCH(c, L::rank1(c, R, a, c->T, c->T, a));

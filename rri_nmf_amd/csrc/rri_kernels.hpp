@@ -209,18 +209,27 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
 // topic tn (CARRY), one thread per row of W.  Gpart[b][0..k) = sum_i wn_i W[i,:], [k] = sum wn_i^2,
 // [k+1] = sum_i W[i,t] (new).  T T[t]^T arrives as nsplit partial vectors from k_tgram.
 // =========================================================================================
+constexpr int WCOL_TILES = 1;   // 64-row tiles per k_wcol block (1 = most blocks in flight)
+constexpr int GRAM_SLICES = 8;  // k_reduce sums the Gpart rows in this many slices; consumers add the slices
+
 template <bool UPDATE, bool CARRY>
 __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, int n, int k, int t, int tn,
                                               const double* __restrict__ Ypart, int npanels,
                                               const double* __restrict__ Ttpart, int nsplit,
                                               double* __restrict__ Gpart, int sweep, KParams p, DevState* st) {
+    // Block = TILES tiles of 64 rows of W (lane = row); its 4 waves split the k columns (wave w takes
+    // l = w, w+4, ...): four times the waves of a row-per-thread layout, dependent chains a quarter as
+    // long.  Gram partials of the tiles add up in LDS (one owner wave per column: fixed order).
     if (st->halt) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* gsh = reinterpret_cast<double*>(smem);   // [4][k+2]
-    double* tts = gsh + 4 * (k + 2);                 // [k]
+    double* tts = reinterpret_cast<double*>(smem);   // [k]
+    double* gsh = tts + k;                           // [k+2] Gram partial of the block
+    double* dsh = gsh + k + 2;                       // [4][64] partial W.Tt per wave
+    double* wsh = dsh + 256;                         // [64] new column entries
     double cden = 0.0;
     int mode = 0;
+    for (int l = tid; l < k + 2; l += 256) gsh[l] = 0.0;
     if (UPDATE) {
         for (int l = tid; l < k; l += 256) {
             double a = 0.0;
@@ -241,62 +250,73 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
                 return;
             }
         }
-        __syncthreads();
     }
-    const i64 i = (i64)blockIdx.x * 256 + tid;
-    const bool valid = i < n;
-    double y = 0.0;
-    if (UPDATE && valid)
-        for (int q = 0; q < npanels; ++q) y += Ypart[(i64)q * n + i];
-    const double wn = (CARRY && valid) ? Wt[(i64)tn * ldw + i] : 0.0;
-    double dotv = 0.0;
-    constexpr int CH = 8;   // loads of 8 columns of W are issued together, then consumed
-    for (int l0 = 0; l0 < k; l0 += CH) {
-        double wl[CH];
+    __syncthreads();
+    constexpr int CH = 16;   // columns per batch of loads per wave (all of a wave's columns when k <= 64)
+    constexpr int TILES = WCOL_TILES;
+    for (int tile = 0; tile < TILES; ++tile) {
+        const i64 i = ((i64)blockIdx.x * TILES + tile) * 64 + lane;
+        if (((i64)blockIdx.x * TILES + tile) * 64 >= n) break;   // block-uniform
+        const bool valid = i < n;
+        const double wn = (CARRY && valid) ? Wt[(i64)tn * ldw + i] : 0.0;
+        double y = 0.0;
+        if (UPDATE && wave == 0 && valid)
+            for (int q = 0; q < npanels; ++q) y += Ypart[(i64)q * n + i];
+        double dotv = 0.0;
+        for (int l0 = wave; l0 < k; l0 += 4 * CH) {
+            double wl[CH];
 #pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const int l = l0 + q;
-            wl[q] = (l < k && valid && !(UPDATE && l == t)) ? Wt[(i64)l * ldw + i] : 0.0;
-        }
+            for (int q = 0; q < CH; ++q) {
+                const int l = l0 + 4 * q;
+                wl[q] = (l < k && valid && !(UPDATE && l == t)) ? Wt[(i64)l * ldw + i] : 0.0;
+            }
 #pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const int l = l0 + q;
-            if (l < k) {   // wave-uniform
-                if (UPDATE) dotv = fma(wl[q], tts[l], dotv);
-                if (CARRY) {
-                    const double g = wave_sum<double>(wn * wl[q]);
-                    if (lane == 0) gsh[wave * (k + 2) + l] = g;
+            for (int q = 0; q < CH; ++q) {
+                const int l = l0 + 4 * q;
+                if (l < k) {   // wave-uniform
+                    if (UPDATE) dotv = fma(wl[q], tts[l], dotv);
+                    if (CARRY && !(UPDATE && l == t)) {
+                        const double g = wave_sum<double>(wn * wl[q]);
+                        if (lane == 0) gsh[l] += g;   // column l belongs to this wave alone
+                    }
                 }
             }
         }
-    }
-    double wnew = 0.0;
-    if (UPDATE && valid) {
-        const double numer = (y - dotv) - p.reg_w_l1;
-        if (mode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
-        else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
-        Wt[(i64)t * ldw + i] = wnew;
-    }
-    {
-        const double gt = wave_sum<double>(wn * wnew);
-        const double nwp = wave_sum<double>(wn * wn);
-        const double swp = wave_sum<double>(wnew);
-        if (lane == 0) {
-            if (UPDATE && CARRY) gsh[wave * (k + 2) + t] = gt;
-            gsh[wave * (k + 2) + k] = nwp;
-            gsh[wave * (k + 2) + k + 1] = swp;
-            if (!CARRY) for (int l = 0; l < k; ++l) gsh[wave * (k + 2) + l] = 0.0;
+        double wnew = 0.0;
+        if (UPDATE) {
+            dsh[wave * 64 + lane] = dotv;
+            __syncthreads();
+            if (wave == 0) {
+                const double dot = (dsh[lane] + dsh[64 + lane]) + (dsh[128 + lane] + dsh[192 + lane]);
+                if (valid) {
+                    const double numer = (y - dot) - p.reg_w_l1;
+                    if (mode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
+                    else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
+                    Wt[(i64)t * ldw + i] = wnew;
+                }
+                wsh[lane] = wnew;
+            }
+            __syncthreads();
+            wnew = wsh[lane];
         }
+        if (wave == 0) {
+            const double nwp = wave_sum<double>(wn * wn);
+            const double swp = wave_sum<double>(wnew);
+            if (lane == 0) { gsh[k] += nwp; gsh[k + 1] += swp; }
+        } else if (wave == 1 && UPDATE && CARRY) {
+            const double gt = wave_sum<double>(wn * wnew);   // Gram entry against the NEW column t
+            if (lane == 0) gsh[t] += gt;
+        }
+        if (UPDATE) __syncthreads();   // dsh / wsh are reused by the next tile
     }
     __syncthreads();
     double* gp = Gpart + (i64)blockIdx.x * (k + 2);
-    for (int l = tid; l < k + 2; l += 256)
-        gp[l] = (gsh[l] + gsh[(k + 2) + l]) + (gsh[2 * (k + 2) + l] + gsh[3 * (k + 2) + l]);
+    for (int l = tid; l < k + 2; l += 256) gp[l] = gsh[l];
 }
 
 // =========================================================================================
 // k_reduce: fixed-order reduction of the row-block partials into the reduce buffer
-//   red[0..ldz) = w^T X ; red[ldz..ldz+k) = w^T W ; red[ldz+k] = ||w||^2 ; red[ldz+k+1] = sum W[:,tprev]
+//   red[0..ldz) = w^T X ; red[ldz + g*(k+2) + ...), g < GRAM_SLICES: slice sums of [w^T W | ||w||^2 | sum W[:,tprev]]
 // (in the row-sharded multi-GPU run this buffer is what the ranks all-reduce).
 // 1024 threads: column blocks take 32 columns x 32 row-block groups, the last block the Gram row.
 // =========================================================================================
@@ -306,8 +326,10 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ Zpar
     if (st->halt) return;
     __shared__ double sh[32 * 33];
     const int tid = threadIdx.x;
-    // Gpart == NULL: column blocks only (the grid then has no Gram block)
-    if (Gpart == nullptr || blockIdx.x + 1 < gridDim.x) {
+    // Gpart == NULL: column blocks only (the grid then has no Gram blocks)
+    const int ngram = Gpart ? GRAM_SLICES : 0;
+    const int nzb = gridDim.x - ngram;
+    if ((int)blockIdx.x < nzb) {
         const int c = tid & 31, g = tid >> 5;
         const i64 j = (i64)blockIdx.x * 32 + c;
         double a = 0.0;
@@ -321,22 +343,34 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ Zpar
             red[j] = s;
         }
     } else {
+        // Gram slice gs: rows [b0, b1) of Gpart, 16 waves striding over them, lanes over the k+2 entries
+        const int gs = blockIdx.x - nzb;
+        const int per = (nwb + GRAM_SLICES - 1) / GRAM_SLICES;
+        const int b0 = gs * per, b1 = min(nwb, b0 + per);
         const int lane = tid & 63, wave = tid >> 6;  // 16 waves
         for (int l0 = 0; l0 < k + 2; l0 += 64) {
             const int l = l0 + lane;
             double a = 0.0;
             if (l < k + 2)
-                for (int b = wave; b < nwb; b += 16) a += Gpart[(i64)b * (k + 2) + l];
+                for (int b = b0 + wave; b < b1; b += 16) a += Gpart[(i64)b * (k + 2) + l];
             __syncthreads();
             sh[wave * 64 + lane] = a;
             __syncthreads();
             if (wave == 0 && l < k + 2) {
                 double s = 0.0;
                 for (int q = 0; q < 16; ++q) s += sh[q * 64 + lane];
-                red[ldz + l] = s;
+                red[ldz + (i64)gs * (k + 2) + l] = s;
             }
         }
     }
+}
+
+// red[ldz + g*(k+2) + l], g < GRAM_SLICES -> entry l of [w^T W | ||w||^2 | sum W[:,tprev]]
+__device__ __forceinline__ double red_gram(const double* __restrict__ red, i64 ldz, int k, int l) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < GRAM_SLICES; ++g) s += red[ldz + (i64)g * (k + 2) + l];
+    return s;
 }
 
 // =========================================================================================
@@ -354,9 +388,9 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
     const int tid = threadIdx.x;
     __shared__ double scratch[40];
     __shared__ double gsh[256];
-    const double nw = red[ldz + k];
+    const double nw = red_gram(red, ldz, k, k);
     if (check_prev) {
-        const double sw = red[ldz + k + 1];
+        const double sw = red_gram(red, ldz, k, k + 1);
         const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
         const bool err = !ev && !(sw > 0.0);
         if (ev || err) {
@@ -384,21 +418,25 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
             return;
         }
     }
-    for (int l = tid; l < k; l += 128) gsh[l] = (l == t) ? 0.0 : red[ldz + l];
+    for (int l = tid; l < k; l += 128) gsh[l] = (l == t) ? 0.0 : red_gram(red, ldz, k, l);
     __syncthreads();
     const i64 j = (i64)blockIdx.x * 128 + tid;
     double x = 0.0, mx = -1.0e300;
     if (j < d) {
-        // gsh[t] == 0, so row t may be read like the others: 4 independent chains keep loads in flight
+        // gsh[t] == 0, so row t may be read like the others; 16 loads are issued before the first use
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int l = 0;
-        for (; l + 4 <= k; l += 4) {
-            a0 = fma(gsh[l + 0], T[(i64)(l + 0) * ldt + j], a0);
-            a1 = fma(gsh[l + 1], T[(i64)(l + 1) * ldt + j], a1);
-            a2 = fma(gsh[l + 2], T[(i64)(l + 2) * ldt + j], a2);
-            a3 = fma(gsh[l + 3], T[(i64)(l + 3) * ldt + j], a3);
+        for (int l0 = 0; l0 < k; l0 += 16) {
+            double tv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tv[q] = (l0 + q < k) ? T[(i64)(l0 + q) * ldt + j] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) {
+                if (l0 + q < k) a0 = fma(gsh[l0 + q], tv[q], a0);
+                if (l0 + q + 1 < k) a1 = fma(gsh[l0 + q + 1], tv[q + 1], a1);
+                if (l0 + q + 2 < k) a2 = fma(gsh[l0 + q + 2], tv[q + 2], a2);
+                if (l0 + q + 3 < k) a3 = fma(gsh[l0 + q + 3], tv[q + 3], a3);
+            }
         }
-        for (; l < k; ++l) a0 = fma(gsh[l], T[(i64)l * ldt + j], a0);
         const double acc = (a0 + a1) + (a2 + a3);
         const double numer = (red[j] - acc) - p.reg_t_l1;
         if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
@@ -519,8 +557,11 @@ __global__ __launch_bounds__(1024) void k_trow_final(double* __restrict__ T, i64
 
 // k_tgram: partial T T[t,:]^T over column slice blockIdx.y: Ttpart[y][l] = <T[l,slice], T[t,slice]>
 // (entry l == t is the slice's share of ||T[t,:]||^2; k_wcol sums the slices, nmf.py:730-734).
+// finish != 0 (no projection configured, so k_trow_numer already stored the row): block (0,0) also does
+// what is left of _project_and_check_reset_t: nt1, sum(T[t,:]) and the reset decision (nmf.py:757-769).
 __global__ __launch_bounds__(256) void k_tgram(const double* __restrict__ T, i64 ldt, int d, int k, int t,
-                                               double* __restrict__ Ttpart, const DevState* __restrict__ st) {
+                                               double* __restrict__ Ttpart, const double* __restrict__ tpart,
+                                               int nblk, int finish, int sweep, KParams p, DevState* st) {
     if (st->halt) return;
     __shared__ double scratch[40];
     const int l = blockIdx.x;
@@ -531,6 +572,19 @@ __global__ __launch_bounds__(256) void k_tgram(const double* __restrict__ T, i64
     for (int j = j0 + threadIdx.x; j < j1; j += 256) acc = fma(T[(i64)l * ldt + j], T[(i64)t * ldt + j], acc);
     acc = block_sum(acc, scratch);
     if (threadIdx.x == 0) Ttpart[blockIdx.y * k + l] = acc;
+    if (finish && blockIdx.x == 0 && blockIdx.y == 0) {
+        double ps = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) ps += tpart[b];
+        ps = block_sum(ps, scratch);
+        if (threadIdx.x == 0) {
+            const int mode = st->tmode;
+            st->nt1 = (mode == 0) ? ps : 1.0;
+            st->sumT = ps;
+            if (!(ps > 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0) {
+                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+            }
+        }
+    }
 }
 
 // W[:,t] *= nt1 (nmf.py:450-452); only observable when fix_W keeps the column.
@@ -545,7 +599,7 @@ __global__ __launch_bounds__(64) void k_check_red(const double* __restrict__ red
                                                   int sweep, int pos, KParams p, DevState* st) {
     if (st->halt) return;
     if (threadIdx.x == 0) {
-        const double sw = red[ldz + k + 1];
+        const double sw = red_gram(red, ldz, k, k + 1);
         const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
         const bool err = !ev && !(sw > 0.0);
         if (ev || err) {

@@ -4,7 +4,7 @@ T replicated.
 A topic step needs ONE cross-row reduction: [w_t^T X (d) | w_t^T W (k) | ||w_t||^2 | sum W[:,t-1]].
 Every rank reduces its shard into the engine's reduce buffer (rri_topic_reduce_local), the ranks
 all-reduce that buffer (float64; RCCL over xGMI through torch.distributed -- the payload is
-(d+k+2)*8 bytes, latency- not link-bound), and the rest of the step is rank-local
+(d + 8(k+2))*8 bytes: the Gram part travels as 8 slice sums; latency- not link-bound), and the rest of the step is rank-local
 (rri_topic_finish): identical T on every rank, own rows of W.
 
 The driver only needs the `step engine` protocol (topic_reduce_local / topic_finish / poll /

@@ -265,8 +265,9 @@ class RRIEngine(object):
         return self._check(self._lib.rri_poll(self._h))
 
     # ---- measurement --------------------------------------------------------------------
-    def timing_enable(self, on=True):
-        self._check(self._lib.rri_timing_enable(self._h, int(bool(on))))
+    def timing_enable(self, on=True, every=1):
+        """HIP-event timing of the streaming kernels; every=N samples each N-th launch"""
+        self._check(self._lib.rri_timing_enable(self._h, int(every) if on else 0))
 
     def timing_read(self, kernel_id):
         cnt, ms = C.c_int64(0), C.c_double(0.0)

@@ -263,6 +263,9 @@ def test_rank1_update_and_copy_bench_run():
         e.sweep(2)
         cnt, ms = e.timing_read(0)
         assert cnt == 2 * 4 + 1 and ms > 0
+        e.timing_enable(True, every=4)
+        e.sweep(2)
+        assert e.timing_read(0)[0] == 2
 
 
 # ---------------------------------------------------------------------------------------------------------

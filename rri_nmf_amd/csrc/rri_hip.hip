@@ -216,15 +216,24 @@ struct LaunchX {
         TimedScope ts(c, 3);
         pass_cfg<true, true, true>(c, R, trow, wc, a, b);
     }
+    template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT>
+    static void wpass_k(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
+                        const double* a2, const double* b2) {
+        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT>), dim3(c->npanels * c->nrb), dim3(256),
+                           11 * (size_t)c->rpb * sizeof(double), c->stream, (SX*)c->E, (const SX*)c->M, c->LD,
+                           c->ldm, (int)c->n, ncols, trow, wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part,
+                           c->LD, c->rpb, c->npanels, (const DevState*)c->st);
+    }
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
     static void wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                       const double* a2, const double* b2) {
         TimedScope ts(c, 3);
-        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
-        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, 4>), dim3(c->npanels * c->nrb), dim3(256),
-                           11 * (size_t)c->rpb * sizeof(double), c->stream, (SX*)c->E, (const SX*)c->M, c->LD,
-                           c->ldm, (int)c->n, ncols, trow, wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part,
-                           c->LD, c->rpb, c->npanels, (const DevState*)c->st);
+        const int u = (g_pass_unroll >= 8) ? 8 : 4;
+        if (u == 8 && g_pass_nt) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 8, true>(c, trow, wc, a1, b1, a2, b2);
+        else if (u == 8) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 8, false>(c, trow, wc, a1, b1, a2, b2);
+        else if (g_pass_nt) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 4, true>(c, trow, wc, a1, b1, a2, b2);
+        else wpass_k<DO_Y, DO_Z, UPD2, WRITE, 4, false>(c, trow, wc, a1, b1, a2, b2);
     }
     static size_t resid_shmem(const rri_ctx* c) {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);

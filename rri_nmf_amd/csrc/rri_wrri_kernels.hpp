@@ -19,7 +19,7 @@ namespace rri {
 // Same block geometry as k_pass: 4 waves = 4 adjacent 1 KiB-wide panels x one row block.
 //   e' = e - m (a1_i b1_j + [UPD2] a2_i b2_j)      (a1,a2: per row, from LDS; b1,b2: per column, registers)
 //   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , Z2part = sum_i w_i^2 m
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U>
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT>
 __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm, int n,
                                                int ncols,
                                                const double* __restrict__ trow, const double* __restrict__ wcol,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 x[u] = XV::zero();
                 mk[u] = XV::zero();
                 if (rr < row1 && ok) {
-                    x[u] = *reinterpret_cast<const V*>(E + (i64)rr * ldx + col);
+                    x[u] = stream_load<NT>(reinterpret_cast<const V*>(E + (i64)rr * ldx + col));
                     mk[u] = stream_load<true>(reinterpret_cast<const V*>(M + (i64)rr * ldm + col));
                 }
             }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 }
                 if constexpr (WRITE) {
                     const V rounded = XV::pack(xe);
-                    if (rr < row1 && ok) *reinterpret_cast<V*>(E + (i64)rr * ldx + col) = rounded;
+                    if (rr < row1 && ok) stream_store<NT>(reinterpret_cast<V*>(E + (i64)rr * ldx + col), rounded);
                     if constexpr (sizeof(SX) == 4) XV::unpack(rounded, xe);
                 }
                 double yp = 0.0, y2p = 0.0;

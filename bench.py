@@ -300,7 +300,16 @@ def main():
             # parity in the same run: the device path on the same sample, equal sweeps (1 + 2)
             from rri_nmf_amd.engine import RRIEngine
             with RRIEngine(rows, d, k, dtype=np.float32, device=local_rank) as e2:
+                e2.upload_X(Xs)                      # warm-up (allocation)
+                tu = time.perf_counter()
                 e2.upload_X(Xs)
+                tu = time.perf_counter() - tu
+                h2d = Xs.nbytes / tu / 1e9
+                out['pcie_inclusive'] = {
+                    'h2d_GBps_pageable': h2d, 'x_upload_ms': 1e3 * bytes_per_launch / (h2d * 1e9),
+                    'note': 'rri_upload_X of the %d-row sample from pageable host memory; uploading the whole X once '
+                            'costs x_upload_ms = %.1f sweeps; never part of `value`'
+                            % (rows, bytes_per_launch / (h2d * 1e9) * sweeps_per_s)}
                 e2.set_W(W0[:rows])
                 e2.set_T(T0)
                 e2.set_params()

@@ -57,6 +57,8 @@ struct rri_ctx {
     bool own_X = false, own_M = false;
     double *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
     double *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Ttpart = nullptr;
+    double* Qt = nullptr;     // X T^T (k x n), valid while T is fixed
+    bool q_valid = false;
     double *Y2part = nullptr, *Z2part = nullptr, *dtv = nullptr, *dwv = nullptr, *wold = nullptr, *zeros = nullptr;  // weighted
     i64 ldw = 0;     // row stride of the k-major W (>= n)
     int nsplit = 4;  // column slices of k_tgram
@@ -235,6 +237,10 @@ struct LaunchX {
         else if (g_pass_nt) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 4, true>(c, trow, wc, a1, b1, a2, b2);
         else wpass_k<DO_Y, DO_Z, UPD2, WRITE, 4, false>(c, trow, wc, a1, b1, a2, b2);
     }
+    static void xtt(rri_ctx* c) {
+        hipLaunchKernelGGL((k_xtt<SX>), dim3((unsigned)((c->n + 63) / 64)), dim3(256), 0, c->stream, (const SX*)c->X,
+                           c->ldx, (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, c->Qt, c->ldw);
+    }
     static size_t resid_shmem(const rri_ctx* c) {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
     }
@@ -282,11 +288,15 @@ struct LaunchX {
 struct LK {  // float64-only kernels
     static size_t wcol_shmem(const rri_ctx* c) { return (size_t)(2 * c->k + 2 + 256 + 64) * sizeof(double); }
     template <bool UPDATE, bool CARRY>
-    static void wcol(rri_ctx* c, int t, int tn, int sweep) {
+    static void wcol_src(rri_ctx* c, int t, int tn, int sweep, const double* ypart, int nslices) {
         TimedScope ts(c, 1);
         hipLaunchKernelGGL((k_wcol<UPDATE, CARRY>), dim3(c->nwb), dim3(256), wcol_shmem(c), c->stream, c->W, c->ldw,
-                           (int)c->n, c->k, t, tn, (const double*)c->Ypart, c->npanels, (const double*)c->Ttpart,
-                           c->nsplit, c->Gpart, sweep, kparams(c), c->st);
+                           (int)c->n, c->k, t, tn, ypart, nslices, (const double*)c->Ttpart, c->nsplit, c->Gpart,
+                           sweep, kparams(c), c->st);
+    }
+    template <bool UPDATE, bool CARRY>
+    static void wcol(rri_ctx* c, int t, int tn, int sweep) {
+        wcol_src<UPDATE, CARRY>(c, t, tn, sweep, (const double*)c->Ypart, c->npanels);
     }
     static void reduce(rri_ctx* c) {
         const int nb = (int)((c->LD + 31) / 32) + GRAM_SLICES;
@@ -462,6 +472,7 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     }
     c->carry_valid = false;
     c->resid_valid = false;
+    c->q_valid = false;   // T changed
 }
 
 void enqueue_W_half(rri_ctx* c, int sweep, int t) {
@@ -470,7 +481,8 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int tn = (t + 1) % k;
     {
         TimedScope ts(c, 2);
-        const int finish = (LK::light(c) && !c->skip_row_finish) ? 1 : 0;
+        // the T-row checks ride on k_tgram only when a T half of this topic just ran and left its sums
+        const int finish = (LK::light(c) && !c->prm.fix_T && !c->skip_row_finish) ? 1 : 0;
         c->skip_row_finish = false;
         LK::tgram(c, t, finish, sweep);
     }
@@ -482,8 +494,17 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
         c->pending_wcheck = true;
         c->pending_wcheck_topic = t;
     } else {
-        DISPATCH(c, (L::template pass<true, false>(c, t, tn)));
-        LK::wcol<true, false>(c, t, tn, sweep);
+        if (c->prm.fix_T) {
+            // T is fixed: X T^T is computed once (k_xtt) and reused by every topic and every sweep
+            if (!c->q_valid) {
+                DISPATCH(c, L::xtt(c));
+                c->q_valid = true;
+            }
+            LK::wcol_src<true, false>(c, t, tn, sweep, c->Qt + (i64)t * c->ldw, 1);
+        } else {
+            DISPATCH(c, (L::template pass<true, false>(c, t, tn)));
+            LK::wcol<true, false>(c, t, tn, sweep);
+        }
         // position of the NEXT step, where a resumed run continues
         int ns = sweep, np = t + 1;
         if (np == k) { np = 0; ns = sweep + 1; }
@@ -700,14 +721,21 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->T, (size_t)k * c->LD * f8));
     CR(hipMemsetAsync(c->T, 0, (size_t)k * c->LD * f8, c->stream));
     CR(hipMalloc((void**)&c->Ypart, (size_t)c->npanels * n * f8));
+    CR(hipMemsetAsync(c->Ypart, 0, (size_t)c->npanels * n * f8, c->stream));
     CR(hipMalloc((void**)&c->Zpart, (size_t)c->nrb * c->LD * f8));
+    CR(hipMemsetAsync(c->Zpart, 0, (size_t)c->nrb * c->LD * f8, c->stream));
     CR(hipMalloc((void**)&c->Gpart, (size_t)c->nwb * (k + 2) * sizeof(double)));
+    CR(hipMemsetAsync(c->Gpart, 0, (size_t)c->nwb * (k + 2) * sizeof(double), c->stream));
     CR(hipMalloc((void**)&c->red, (size_t)c->red_elems * f8));
     CR(hipMemsetAsync(c->red, 0, (size_t)c->red_elems * f8, c->stream));
     c->own_red = true;
     CR(hipMalloc((void**)&c->xraw, (size_t)c->LD * f8));
+    CR(hipMemsetAsync(c->xraw, 0, (size_t)c->LD * f8, c->stream));
     CR(hipMalloc((void**)&c->Ttpart, (size_t)c->nsplit * k * f8));
+    CR(hipMemsetAsync(c->Ttpart, 0, (size_t)c->nsplit * k * f8, c->stream));
+    CR(hipMalloc((void**)&c->Qt, (size_t)k * c->ldw * f8));
     CR(hipMalloc((void**)&c->tpart, (size_t)c->ntb * sizeof(double)));
+    CR(hipMemsetAsync(c->tpart, 0, (size_t)c->ntb * sizeof(double), c->stream));
     CR(hipMalloc((void**)&c->tpart_idx, (size_t)c->ntb * sizeof(i64)));
     CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
     CR(hipMalloc((void**)&c->dtmp, 16 * sizeof(double)));
@@ -744,7 +772,7 @@ rri_status rri_destroy(rri_ctx* c) {
     void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
-                    (void*)c->Z2part, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros};
+                    (void*)c->Z2part, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -768,7 +796,7 @@ rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_d
     }
     c->ldx = c->LD;
     rri_status s = to_device(c, host, ld, host_dtype, c->X, c->ldx, c->n, c->d, c->dtype);
-    if (s == RRI_OK) { c->have_X = true; invalidate(c); }
+    if (s == RRI_OK) { c->have_X = true; invalidate(c); c->q_valid = false; }
     return s;
 }
 
@@ -799,6 +827,7 @@ rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     c->ldx = ld;
     c->have_X = true;
     invalidate(c);
+    c->q_valid = false;
     return RRI_OK;
 }
 
@@ -828,7 +857,7 @@ rri_status rri_set_T(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtyp
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
     rri_status s = to_device(c, host, ld, host_dtype, c->T, c->LD, c->k, c->d, RRI_F64);
-    if (s == RRI_OK) { c->have_T = true; invalidate(c); }
+    if (s == RRI_OK) { c->have_T = true; invalidate(c); c->q_valid = false; }
     return s;
 }
 rri_status rri_get_W(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
@@ -896,6 +925,7 @@ rri_status rri_pending_event(rri_ctx* c, rri_event* ev) {
 }
 
 static void event_resolved(rri_ctx* c) {
+    c->q_valid = false;   // a reset rewrites T[t,:] even when T is otherwise fixed (nmf.py:808,814)
     if (c->pending.kind == RRI_EVENT_RESET_T) c->skip_row_finish = true;
     c->pending.kind = RRI_EVENT_NONE;
     if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
@@ -1112,6 +1142,7 @@ rri_status rri_rollback(rri_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->T, c->Tprev, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate(c);
+    c->q_valid = false;
     c->pending_wcheck = false;
     return RRI_OK;
 }

@@ -738,6 +738,61 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
     }
 }
 
+// =========================================================================================
+// k_xtt: Qt = (X T^T)^T, k x n k-major: the row products X T[l,:]^T of ALL topics in one pass over X.
+// Used when T is fixed (fold-in / transform, nmf.py:417 `fix_T`): X T^T does not change between
+// sweeps, so every later W-column update reads its X t_t from Qt instead of streaming X again.
+// Block = 64 rows; threads = 16 row groups (4 rows) x 16 topic lanes (topics tx, tx+16, tx+32, tx+48);
+// topics beyond 64 are done in further rounds.  A dense k-panel GEMM on the f64 vector ALU.
+// =========================================================================================
+template <typename SX>
+__global__ __launch_bounds__(256) void k_xtt(const SX* __restrict__ X, i64 ldx, const double* __restrict__ T, i64 ldt,
+                                             int n, int d, int k, double* __restrict__ Qt, i64 ldq) {
+    constexpr int CT = 32;   // columns per LDS tile
+    __shared__ double Xsh[64][CT + 1];
+    __shared__ double Tsh[64][CT + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const i64 row0 = (i64)blockIdx.x * 64;
+    for (int l0 = 0; l0 < k; l0 += 64) {
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int c0 = 0; c0 < d; c0 += CT) {
+            __syncthreads();
+            for (int idx = tid; idx < 64 * CT; idx += 256) {
+                const int r = idx / CT, c = idx - r * CT;
+                Xsh[r][c] = (row0 + r < n && c0 + c < d) ? (double)X[(row0 + r) * ldx + c0 + c] : 0.0;
+                Tsh[r][c] = (l0 + r < k && c0 + c < d) ? T[(i64)(l0 + r) * ldt + c0 + c] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int c = 0; c < CT; ++c) {
+                double xv[4], tv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xv[a] = Xsh[ty * 4 + a][c];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) tv[b] = Tsh[tx + 16 * b][c];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(xv[a], tv[b], acc[a][b]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int l = l0 + tx + 16 * b;
+            if (l >= k) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const i64 i = row0 + ty * 4 + a;
+                if (i < n) Qt[(i64)l * ldq + i] = acc[a][b];
+            }
+        }
+    }
+}
+
 // partial sums of v, v^2 and |v| over a strided matrix: out[b] = {sum, sumsq, sumabs}
 __global__ __launch_bounds__(256) void k_norms(const double* __restrict__ A, i64 rows, i64 cols, i64 ld,
                                                double* __restrict__ out) {

@@ -162,8 +162,9 @@ def test_text_fixture_topic_assignments_are_exact(dtype):
         e.upload_X(X); e.set_W(W); e.set_T(T); e.set_params()
         assert np.array_equal(e.argmax_rows(), g['argmax_s10'])
     # fold-in of held-out documents (G2): fix_T, 4 sweeps, final projection
-    Wte, _, _ = run_engine(g['Xte'], g['Wte0'], g['T_s10'], 4, dtype, final_proj=1.0, fix_T=True,
-                           t_row_sum=1.0, w_row_sum=1.0)
+    Wte, Tte, nres = run_engine(g['Xte'], g['Wte0'], g['T_s10'], 4, dtype, final_proj=1.0, fix_T=True,
+                                t_row_sum=1.0, w_row_sum=1.0)
+    assert nres == 0 and np.array_equal(Tte, g['T_s10'])      # T untouched, no reset events
     assert relfro(Wte, g['Wte']) < (TOL[dtype] if dtype == np.float64 else 1e-6)
     assert np.array_equal(np.argmax(Wte, 1), g['argmax_te'])
 

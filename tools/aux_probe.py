@@ -23,3 +23,9 @@ with RRIEngine(n, d, k, dtype=np.float32) as e:
     print('set_W           %.2f ms' % timed(lambda: e.set_W(W0)))
     print('argmax_rows     %.2f ms' % timed(e.argmax_rows))
     print('snapshot        %.2f ms' % timed(lambda: (e.snapshot(), e.synchronize())))
+
+    e.set_params(fix_T=True, w_row_sum=1.0, t_row_sum=1.0)
+    t0 = time.perf_counter(); e.sweep(4); e.project_W_rows(1.0); dt = time.perf_counter() - t0
+    print('fold-in (fix_T, 4 sweeps + projection) first call  %.2f ms' % (dt * 1e3))
+    t0 = time.perf_counter(); e.sweep(4); dt = time.perf_counter() - t0
+    print('fold-in 4 more sweeps (X T^T cached)              %.2f ms' % (dt * 1e3))

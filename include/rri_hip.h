@@ -73,10 +73,11 @@ typedef struct rri_params {
 } rri_params;
 
 typedef struct rri_event {
-    int32_t kind;    /* RRI_EVENT_* */
-    int32_t topic;   /* t */
-    int32_t sweep;   /* sweep index inside the interrupted rri_sweep call */
-    int32_t reserved;
+    int32_t kind;          /* RRI_EVENT_* */
+    int32_t topic;         /* t: the row of T / column of W to reset */
+    int32_t sweep;         /* sweep index (inside the interrupted call) of the step that detected it */
+    int32_t resume_topic;  /* topic of that step: a RESET_T resumes at the W half of `topic`, a RESET_W at
+                              the T half of `resume_topic` */
 } rri_event;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -149,6 +150,13 @@ rri_status rri_reduce_buffer(rri_ctx* ctx, void** dev_ptr, int64_t* n_elems); /*
 rri_status rri_bind_reduce_buffer(rri_ctx* ctx, void* dev_ptr, int64_t n_elems);
 rri_status rri_topic_reduce_local(rri_ctx* ctx, int32_t t);
 rri_status rri_topic_finish(rri_ctx* ctx, int32_t t);
+/* only the W-column half of topic t (a sharded run resuming after a T-row reset) */
+rri_status rri_topic_finish_w(rri_ctx* ctx, int32_t t);
+/* Pieces of the 'max_resid_document' reset for a sharded run (nmf.py:771-776): the largest
+ * sum_j max(X - W T, 0)_ij^2 over THIS rank's rows and its local row index; and the reset row
+ * max(X[i,:] - W[i,:] T, 0) of a local row (d doubles to the host).  The caller picks the global winner. */
+rri_status rri_resid_row_argmax(rri_ctx* ctx, double* value, int64_t* local_row);
+rri_status rri_reset_row(rri_ctx* ctx, int64_t local_row, double* row_out_host);
 /* status word of the interrupted / failed step after a stream sync (same codes as rri_sweep) */
 rri_status rri_poll(rri_ctx* ctx);
 /* rank-local pieces of the objective: out[0] = 0.5*sum (Wm.)(X-WT)^2 over local rows,

@@ -31,7 +31,7 @@ class Params(C.Structure):
 
 class Event(C.Structure):
     """struct rri_event"""
-    _fields_ = [('kind', C.c_int32), ('topic', C.c_int32), ('sweep', C.c_int32), ('reserved', C.c_int32)]
+    _fields_ = [('kind', C.c_int32), ('topic', C.c_int32), ('sweep', C.c_int32), ('resume_topic', C.c_int32)]
 
 
 _P = C.c_void_p
@@ -69,6 +69,9 @@ PROTOTYPES = {
     'rri_bind_reduce_buffer': (_I32, [_P, _P, _I64]),
     'rri_topic_reduce_local': (_I32, [_P, _I32]),
     'rri_topic_finish': (_I32, [_P, _I32]),
+    'rri_topic_finish_w': (_I32, [_P, _I32]),
+    'rri_resid_row_argmax': (_I32, [_P, C.POINTER(_D), C.POINTER(_I64)]),
+    'rri_reset_row': (_I32, [_P, _I64, C.POINTER(_D)]),
     'rri_poll': (_I32, [_P]),
     'rri_objective_parts': (_I32, [_P, C.POINTER(_D)]),
     'rri_timing_enable': (_I32, [_P, _I32]),

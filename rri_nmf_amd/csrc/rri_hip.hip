@@ -623,6 +623,7 @@ rri_status status_from_halt(rri_ctx* c, const DevState& s, int32_t* sweeps_done)
         c->pending.kind = s.halt == HALT_EVENT_RESET_T ? RRI_EVENT_RESET_T : RRI_EVENT_RESET_W;
         c->pending.topic = s.halt_topic;
         c->pending.sweep = s.halt_sweep;
+        c->pending.resume_topic = s.halt_pos;
         if (s.halt == HALT_EVENT_RESET_T) c->resume_at = Cursor{s.halt_sweep, s.halt_topic, 1};
         else c->resume_at = Cursor{s.halt_sweep, s.halt_pos, 0};
         if (sweeps_done) *sweeps_done = s.halt_sweep;
@@ -973,6 +974,8 @@ rri_status rri_skip_reset(rri_ctx* c) {
     if (!c->paused) return fail(c, RRI_ERR_INVALID, "no pending event");
     c->pending.kind = RRI_EVENT_NONE;
     c->prm.resets_left = 0;
+    rri_status r = clear_halt(c);
+    if (r != RRI_OK) return r;
     return RRI_OK;
 }
 
@@ -1207,6 +1210,45 @@ rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     return RRI_OK;
 }
 
+rri_status rri_topic_finish_w(rri_ctx* c, int32_t t) {
+    CHECK_CTX(c);
+    if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->skip_row_finish = true;   // the T-row sums of this topic predate the reset
+    enqueue_W_half(c, 0, t);
+    return RRI_OK;
+}
+
+rri_status rri_resid_row_argmax(rri_ctx* c, double* value, int64_t* local_row) {
+    CHECK_CTX(c);
+    if (!value || !local_row) return fail(c, RRI_ERR_INVALID, "NULL output");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->rowpos) HIPCHK(c, hipMalloc((void**)&c->rowpos, (size_t)c->n * sizeof(double)));
+    DISPATCH(c, L::resid(c, false, false, nullptr, c->rowpos));
+    hipLaunchKernelGGL(k_vec_sum_argmax, dim3(1), dim3(1024), 0, c->stream, (const double*)c->rowpos, c->n,
+                       (double*)nullptr, c->itmp);
+    i64 mi = -1;
+    HIPCHK(c, hipMemcpyAsync(&mi, c->itmp, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mi < 0 || mi >= c->n) return fail(c, RRI_ERR_INVALID, "arg-max out of range");
+    HIPCHK(c, hipMemcpyAsync(value, c->rowpos + mi, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *local_row = mi;
+    return RRI_OK;
+}
+
+rri_status rri_reset_row(rri_ctx* c, int64_t local_row, double* row_out_host) {
+    CHECK_CTX(c);
+    if (!row_out_host || local_row < 0 || local_row >= c->n) return fail(c, RRI_ERR_INVALID, "bad row");
+    HIPCHK(c, hipSetDevice(c->device));
+    const i64 mi = local_row;
+    HIPCHK(c, hipMemcpyAsync(c->itmp, &mi, sizeof(i64), hipMemcpyHostToDevice, c->stream));
+    DISPATCH(c, L::reset_row(c));
+    HIPCHK(c, hipMemcpyAsync(row_out_host, c->xraw, (size_t)c->d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
 rri_status rri_poll(rri_ctx* c) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1215,7 +1257,7 @@ rri_status rri_poll(rri_ctx* c) {
     if (r != RRI_OK) return r;
     c->run_total = 0;
     r = status_from_halt(c, s, nullptr);
-    if (s.halt != 0) (void)clear_halt(c);
+    if (s.halt < 0) (void)clear_halt(c);   // an event stays latched until rri_apply_reset_* / rri_skip_reset
     return r;
 }
 

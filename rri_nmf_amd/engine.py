@@ -261,8 +261,35 @@ class RRIEngine(object):
     def topic_finish(self, t):
         self._check(self._lib.rri_topic_finish(self._h, int(t)))
 
+    def topic_finish_w(self, t):
+        self._check(self._lib.rri_topic_finish_w(self._h, int(t)))
+
     def poll(self):
+        """synchronises and returns RRI_OK or RRI_PAUSED (errors raise)"""
         return self._check(self._lib.rri_poll(self._h))
+
+    def pending_event(self):
+        ev = Event()
+        self._check(self._lib.rri_pending_event(self._h, C.byref(ev)))
+        return ev.kind, ev.topic, ev.resume_topic
+
+    def resid_row_argmax(self):
+        val, row = C.c_double(0.0), C.c_int64(-1)
+        self._check(self._lib.rri_resid_row_argmax(self._h, C.byref(val), C.byref(row)))
+        return float(val.value), int(row.value)
+
+    def reset_row(self, local_row):
+        out = np.empty(self.d, dtype=np.float64)
+        self._check(self._lib.rri_reset_row(self._h, int(local_row), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def apply_reset_vectors(self, t, T_row, W_col):
+        T_row = np.ascontiguousarray(T_row, dtype=np.float64)
+        W_col = np.ascontiguousarray(W_col, dtype=np.float64)
+        self._check(self._lib.rri_apply_reset_vectors(
+            self._h, int(t), T_row.ctypes.data_as(C.POINTER(C.c_double)),
+            W_col.ctypes.data_as(C.POINTER(C.c_double))))
+        self.n_resets_used += 1
 
     # ---- measurement --------------------------------------------------------------------
     def timing_enable(self, on=True, every=1):

@@ -224,3 +224,40 @@ def test_convergence_RS_Estimator():
     assert abs(E2.score(X) - float(g['rs_noes_score'])) < 1e-4
     Wnew = E2.transform(g['Xte'].astype(np.float64))
     assert Wnew.shape == (n, 5) and Wnew.min() >= 0
+
+
+def test_sharded_resets_match_single_call_path():
+    """reset events in the row-sharded stepping (resolved collectively by ShardedRRI) give what rri_sweep's own
+    pause / resolve / resume gives: W columns killed (events noticed by the next T-row step, the last one by the
+    final check) and T rows killed (events inside a topic step)"""
+    import os
+    import torch.distributed as dist
+    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
+    from rri_nmf_amd.engine import RRIEngine
+    g = load_golden('g6_rare_branches')
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=3, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=4)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29618')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        for flags, gW, gT in ((dict(t_row_sum=1.0, reg_w_l1=1e6), 'l1killW_mrd_W', 'l1killW_mrd_T'),
+                              (dict(t_row_sum=1.0, reg_t_l1=1e6), 'l1kill_W', 'l1kill_T')):
+            with RRIEngine(n, d, k, dtype=np.float64) as e:
+                e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params(**flags)
+                e.sweep(2)
+                Wa, Ta, na = e.get_W(), e.get_T(), e.n_resets_used
+            eng, red, stream = make_device_shard(n, d, k, dtype=np.float64, device_index=0)
+            eng.upload_X(X); eng.set_W(W0); eng.set_T(T0); eng.set_params(**flags)
+            drv = ShardedRRI(eng, red, k, stream=stream, row_lo=0, n_global=n)
+            drv.sweep(1)
+            W1, T1 = eng.get_W(), eng.get_T()
+            assert relfro(W1, g[gW]) < TOL and relfro(T1, g[gT]) < TOL        # the reference's vectors after 1 sweep
+            drv.sweep(1)
+            Wb, Tb = eng.get_W(), eng.get_T()
+            eng.close()
+            assert drv.n_resets_used == na and na >= k
+            assert relfro(Wb, Wa) < 1e-12 and relfro(Tb, Ta) < 1e-12
+    finally:
+        dist.destroy_process_group()

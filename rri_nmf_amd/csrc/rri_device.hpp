@@ -95,6 +95,28 @@ __device__ __forceinline__ i64 wave_sum_i64(i64 v) {
     return (i64)d;
 }
 
+// Sums of 8 rows at once: v[u] is this lane's partial of row u (u < 8).  The wave parks the 8 x 64 partials in
+// a PRIVATE LDS tile (8 rows x 72 doubles, padded), re-reads them transposed -- lane = (row r = lane>>3,
+// part p = lane&7) adds the 8 partials p*8..p*8+7 of row r -- and three DPP steps add the 8 parts.  Returns
+// the total of row (lane>>3), identical in the 8 lanes of that row group.  About 4 ops per row instead of the
+// 18 of six f64 DPP steps.  LDS instructions of one wave execute in issue order, so only the compiler needs
+// a fence between the stores and the loads.
+__device__ __forceinline__ double wave_rowsum8(const double (&v)[8], double* tile, int lane) {
+    const int wpos = lane + (lane >> 3);              // column `lane` of a row, padded by one per 8
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[u * 72 + wpos] = v[u];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int r = lane >> 3, p = lane & 7;
+    const double* src = tile + r * 72 + p * 9;        // columns p*8 .. p*8+7 of row r
+    double s = ((src[0] + src[1]) + (src[2] + src[3])) + ((src[4] + src[5]) + (src[6] + src[7]));
+    s += dpp<0xB1, 0xf>(s);      // quad_perm [1,0,3,2]
+    s += dpp<0x4E, 0xf>(s);      // quad_perm [2,3,0,1]
+    s += dpp<0x141, 0xf>(s);     // row_half_mirror: the other quad of the 8-lane group
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+
 // max with first-index tie-break over a fully active wave (butterfly through LDS-free shuffles)
 __device__ __forceinline__ void wave_argmax(double& v, i64& idx) {
 #pragma unroll

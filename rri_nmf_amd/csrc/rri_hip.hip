@@ -57,6 +57,8 @@ struct rri_ctx {
     bool own_X = false, own_M = false;
     double *W = nullptr, *T = nullptr, *Wprev = nullptr, *Tprev = nullptr;
     double *Ypart = nullptr, *Zpart = nullptr, *red = nullptr, *xraw = nullptr, *Ttpart = nullptr;
+    unsigned* Mbits = nullptr;   // bit-packed 0/1 mask (weighted flavour), ldb words per row; NULL = fp mask in M
+    i64 ldb = 0;
     double* Qt = nullptr;     // X T^T (k x n), valid while T is fixed
     bool q_valid = false;
     double *Y2part = nullptr, *Z2part = nullptr, *dtv = nullptr, *dwv = nullptr, *wold = nullptr, *zeros = nullptr;  // weighted
@@ -178,33 +180,38 @@ struct TimedScope {
 
 // ---- typed launch helpers ------------------------------------------------------------------
 // geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
-int g_pass_unroll = 8, g_pass_nt = 1;
+int g_pass_unroll = 8, g_pass_nt = 1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8)
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
 template <typename SX>
 struct LaunchX {
-    static size_t pass_shmem(const rri_ctx* c) { return 6 * (size_t)c->rpb * sizeof(double); }
-    template <bool DO_Y, bool DO_Z, bool UPD, int U, bool NT>
+    static size_t pass_shmem(const rri_ctx* c) { return (6 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
+    template <bool DO_Y, bool DO_Z, bool UPD, int U, bool NT, bool RS>
     static void pass_k(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
         typedef typename std::conditional<UPD, SX, const SX>::type XT;
-        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT>), dim3(c->npanels * c->nrb), dim3(256),
+        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb), dim3(256),
                            pass_shmem(c), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
                            c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st);
     }
     template <bool DO_Y, bool DO_Z, bool UPD>
     static void pass_cfg(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a,
                          const double* b) {
+        if (g_pass_unroll == 8 && g_pass_rs && DO_Y) {
+            if (g_pass_nt) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, trow, wc, a, b);
+            else pass_k<DO_Y, DO_Z, UPD, 8, false, true>(c, Xp, trow, wc, a, b);
+            return;
+        }
         const int key = g_pass_unroll * 2 + (g_pass_nt ? 1 : 0);
         switch (key) {
-#define RRI_CASE(U_)                                                                      \
-    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false>(c, Xp, trow, wc, a, b); break;   \
-    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true>(c, Xp, trow, wc, a, b); break;
+#define RRI_CASE(U_)                                                                            \
+    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false, false>(c, Xp, trow, wc, a, b); break;   \
+    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true, false>(c, Xp, trow, wc, a, b); break;
             RRI_CASE(4)
             RRI_CASE(8)
             RRI_CASE(16)
 #undef RRI_CASE
-            default: pass_k<DO_Y, DO_Z, UPD, 8, true>(c, Xp, trow, wc, a, b);
+            default: pass_k<DO_Y, DO_Z, UPD, 8, true, false>(c, Xp, trow, wc, a, b);
         }
     }
     // row dots against T[t,:] (DO_Y) and column sums against W[:,tz] (DO_Z)
@@ -218,24 +225,52 @@ struct LaunchX {
         TimedScope ts(c, 3);
         pass_cfg<true, true, true>(c, R, trow, wc, a, b);
     }
-    template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT>
+    template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, bool MBITS, int U, bool RS>
     static void wpass_k(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                         const double* a2, const double* b2) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
-        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT>), dim3(c->npanels * c->nrb), dim3(256),
-                           11 * (size_t)c->rpb * sizeof(double), c->stream, (SX*)c->E, (const SX*)c->M, c->LD,
-                           c->ldm, (int)c->n, ncols, trow, wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part,
-                           c->LD, c->rpb, c->npanels, (const DevState*)c->st);
+        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS>), dim3(c->npanels * c->nrb),
+                           dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
+                           (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
+                           wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
+                           (const DevState*)c->st);
     }
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
     static void wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                       const double* a2, const double* b2) {
         TimedScope ts(c, 3);
-        const int u = (g_pass_unroll >= 8) ? 8 : 4;
-        if (u == 8 && g_pass_nt) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 8, true>(c, trow, wc, a1, b1, a2, b2);
-        else if (u == 8) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 8, false>(c, trow, wc, a1, b1, a2, b2);
-        else if (g_pass_nt) wpass_k<DO_Y, DO_Z, UPD2, WRITE, 4, true>(c, trow, wc, a1, b1, a2, b2);
-        else wpass_k<DO_Y, DO_Z, UPD2, WRITE, 4, false>(c, trow, wc, a1, b1, a2, b2);
+        // rows in flight: 8 for the passes that take row products (they use the LDS row sums), 4 for the
+        // writing pass (two rank-one corrections and two sets of accumulators: 4 rows keep it at 4 waves/SIMD)
+        constexpr int U = DO_Y ? 8 : 4;
+        const bool rs = DO_Y && g_pass_rs;
+        if (c->Mbits) {
+            if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
+            else wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, U, false>(c, trow, wc, a1, b1, a2, b2);
+        } else {
+            if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
+            else wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, U, false>(c, trow, wc, a1, b1, a2, b2);
+        }
+    }
+    // 0/1 masks are bit-packed (32 columns per word): the mask then costs 1/32 of its fp32 bytes per pass
+    static rri_status pack_mask_if_binary(rri_ctx* c) {
+        if (c->Mbits) { (void)hipFree(c->Mbits); c->Mbits = nullptr; }
+        if (const char* e = getenv("RRI_MASK_BITS")) if (atoi(e) == 0) return RRI_OK;
+        hipError_t err = hipMemsetAsync(c->itmp, 0, sizeof(i64), c->stream);
+        if (err != hipSuccess) return RRI_ERR_HIP;
+        hipLaunchKernelGGL((k_mask_nonbinary<SX>), dim3(2048), dim3(256), 0, c->stream, (const SX*)c->M, c->ldm,
+                           c->n, c->d, (int*)c->itmp);
+        int bad = 1;
+        err = hipMemcpyAsync(&bad, c->itmp, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+        if (err != hipSuccess) return RRI_ERR_HIP;
+        if (bad) return RRI_OK;
+        c->ldb = (c->LD + 31) / 32;
+        err = hipMalloc((void**)&c->Mbits, (size_t)c->n * c->ldb * sizeof(unsigned));
+        if (err != hipSuccess) { c->Mbits = nullptr; return RRI_ERR_HIP; }
+        hipLaunchKernelGGL((k_mask_pack<SX>), dim3(4096), dim3(256), 0, c->stream, (const SX*)c->M, c->ldm, c->n,
+                           c->d, c->Mbits, c->ldb);
+        err = hipStreamSynchronize(c->stream);
+        return err == hipSuccess ? RRI_OK : RRI_ERR_HIP;
     }
     static void xtt(rri_ctx* c) {
         hipLaunchKernelGGL((k_xtt<SX>), dim3((unsigned)((c->n + 63) / 64)), dim3(256), 0, c->stream, (const SX*)c->X,
@@ -249,8 +284,8 @@ struct LaunchX {
         const size_t sh = resid_shmem(c);
 #define RRI_RESID(MK, WE)                                                                                       \
     hipLaunchKernelGGL((k_resid<SX, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const SX*)c->X, c->ldx,      \
-                       (const SX*)c->M, c->ldm, (const double*)c->W, c->ldw, (const double*)c->T, c->LD,       \
-                       (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+                       (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,   \
+                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
         if (masked && write_e) RRI_RESID(true, true);
         else if (masked) RRI_RESID(true, false);
         else if (write_e) RRI_RESID(false, true);
@@ -682,6 +717,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->VN = (int)(16 / c->es);
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) g_pass_unroll = v; }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
+    if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
 #define CR(call)                                                                                   \
@@ -773,7 +809,7 @@ rri_status rri_destroy(rri_ctx* c) {
     void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
-                    (void*)c->Z2part, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros};
+                    (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -813,7 +849,13 @@ rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t hos
     }
     c->ldm = c->LD;
     rri_status s = to_device(c, host, ld, host_dtype, c->M, c->ldm, c->n, c->d, c->dtype);
-    if (s == RRI_OK) { c->have_M = true; invalidate(c); }
+    if (s == RRI_OK) {
+        c->have_M = true;
+        invalidate(c);
+        DISPATCH(c, s = L::pack_mask_if_binary(c));
+        if (s != RRI_OK) return fail(c, s, "packing the mask failed");
+        if (c->Mbits && c->own_M) { (void)hipFree(c->M); c->M = nullptr; c->own_M = false; }   // bits replace it
+    }
     return s;
 }
 
@@ -844,6 +886,9 @@ rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
     c->ldm = ld;
     c->have_M = true;
     invalidate(c);
+    rri_status ps = RRI_OK;
+    DISPATCH(c, ps = L::pack_mask_if_binary(c));
+    if (ps != RRI_OK) return fail(c, ps, "packing the mask failed");
     return RRI_OK;
 }
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void stream_store(V* p, const V& v) {
 // Every wave walks all rows of the block, U rows in flight; the 4 row-dot partials of a row meet in
 // LDS slots [wave][row] and are added in a fixed order at the end (Ypart has one slice per 4 panels);
 // column sums belong to one wave each and go straight to Zpart.
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD, int U, bool NT>
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD, int U, bool NT, bool RS>
 __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX, const SX>::type* __restrict__ X,
                                               i64 ldx, int n, int ncols,
                                               const double* __restrict__ trow, const double* __restrict__ wcol,
@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
     double* ysh = reinterpret_cast<double*>(smem);            // [4 waves][rpb]
     double* wsh = ysh + 4 * rpb;                              // [rpb]
     double* ash = wsh + rpb;                                  // [rpb] (UPD)
+    static_assert(!RS || U == 8, "the LDS row-sum path reduces 8 rows at a time");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* tile = ash + rpb + wave * (8 * 72);               // [4][8*72] private row-sum tiles (RS)
     const int pg = blockIdx.x % npg;
     const int rb = blockIdx.x / npg;
     const int row0 = rb * rpb;
@@ -176,9 +178,13 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
                     if (DO_Y) yp = fma(xe[e], tv[e], yp);
                     if (DO_Z) zacc[e] = fma(wv, xe[e], zacc[e]);
                 }
-                if (DO_Y) ys[u] = wave_sum<double>(yp);
+                if (DO_Y) ys[u] = RS ? yp : wave_sum<double>(yp);
             }
-            if (DO_Y) {
+            if constexpr (DO_Y && RS) {
+                const double tot = wave_rowsum8(reinterpret_cast<const double (&)[8]>(ys), tile, lane);
+                const int rr = r + (lane >> 3);
+                if ((lane & 7) == 0 && rr < row1) ysh[wave * rpb + rr - row0] = tot;
+            } else if (DO_Y) {
                 double yv = ys[0];
 #pragma unroll
                 for (int u = 1; u < U; ++u)
@@ -663,6 +669,7 @@ __global__ __launch_bounds__(256) void k_proj_rows(double* __restrict__ Wt, i64 
 // =========================================================================================
 template <typename SX, bool MASKED, bool WRITE_E>
 __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M, i64 ldm,
+                                               const unsigned* __restrict__ Mb, i64 ldb,
                                                const double* __restrict__ Wt, i64 ldw, const double* __restrict__ T,
                                                i64 ldt, int n, int d, int k, double* __restrict__ rowobj,
                                                double* __restrict__ rowpos, SX* __restrict__ E, i64 lde) {
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
                 const i64 j = c0 + tx * 4 + b;
                 if (j >= d) continue;
                 S e = (S)X[i * ldx + j] - acc[a][b];
-                const S m = MASKED ? (S)M[i * ldm + j] : S(1);
+                const S m = !MASKED ? S(1) : (Mb ? (S)((Mb[i * ldb + (j >> 5)] >> (j & 31)) & 1u) : (S)M[i * ldm + j]);
                 if (WRITE_E) E[i * lde + j] = (SX)(m * e);
                 so[a] += (double)m * (double)e * (double)e;
                 const double ep = e > S(0) ? (double)e : 0.0;

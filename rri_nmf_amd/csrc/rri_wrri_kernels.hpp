@@ -16,12 +16,70 @@
 
 namespace rri {
 
+// The weights W_mat reach the kernels either as an SX array or, when every entry is 0 or 1 (the recommender
+// case: observed / not observed), bit-packed: row-major, one uint32 per 32 columns.  A lane's VN consecutive
+// columns sit in one word.
+template <typename SX, bool MBITS>
+struct MaskLoad {
+    typedef typename XVec<SX>::type V;
+    static constexpr int VN = XVec<SX>::N;
+    // what stays in registers while U rows are in flight: one word (bits) or one 16-byte vector
+    typedef typename std::conditional<MBITS, unsigned, V>::type Raw;
+    static __device__ __forceinline__ Raw zero() {
+        if constexpr (MBITS) return 0u;
+        else return XVec<SX>::zero();
+    }
+    static __device__ __forceinline__ Raw load(const SX* __restrict__ M, i64 ldm, const unsigned* __restrict__ Mb,
+                                               i64 ldb, i64 row, int col) {
+        if constexpr (MBITS) return Mb[row * ldb + (col >> 5)] >> (col & 31);
+        else return stream_load<true>(reinterpret_cast<const V*>(M + row * ldm + col));
+    }
+    static __device__ __forceinline__ void expand(const Raw& r, double (&me)[VN]) {
+        if constexpr (MBITS) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) me[e] = (double)((r >> e) & 1u);
+        } else {
+            XVec<SX>::unpack(r, me);
+        }
+    }
+};
+
+// out[0] != 0 when some entry of M is neither 0 nor 1
+template <typename SX>
+__global__ __launch_bounds__(256) void k_mask_nonbinary(const SX* __restrict__ M, i64 ldm, i64 n, i64 d,
+                                                        int* __restrict__ out) {
+    int bad = 0;
+    const i64 total = n * d;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 r = idx / d, c = idx - r * d;
+        const SX v = M[r * ldm + c];
+        if (!(v == SX(0) || v == SX(1))) bad = 1;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(out, 1);
+}
+
+// Mb[r][w] bit b = (M[r][32 w + b] != 0); columns beyond d are 0
+template <typename SX>
+__global__ __launch_bounds__(256) void k_mask_pack(const SX* __restrict__ M, i64 ldm, i64 n, i64 d,
+                                                   unsigned* __restrict__ Mb, i64 ldb) {
+    const i64 total = n * ldb;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 r = idx / ldb, w = idx - r * ldb;
+        unsigned bits = 0;
+        for (int b = 0; b < 32; ++b) {
+            const i64 c = w * 32 + b;
+            if (c < d && M[r * ldm + c] != SX(0)) bits |= (1u << b);
+        }
+        Mb[idx] = bits;
+    }
+}
+
 // Same block geometry as k_pass: 4 waves = 4 adjacent 1 KiB-wide panels x one row block.
 //   e' = e - m (a1_i b1_j + [UPD2] a2_i b2_j)      (a1,a2: per row, from LDS; b1,b2: per column, registers)
 //   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , Z2part = sum_i w_i^2 m
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT>
-__global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm, int n,
-                                               int ncols,
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
+__global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm,
+                                               const unsigned* __restrict__ Mb, i64 ldb, int n, int ncols,
                                                const double* __restrict__ trow, const double* __restrict__ wcol,
                                                const double* __restrict__ a1v, const double* __restrict__ b1v,
                                                const double* __restrict__ a2v, const double* __restrict__ b2v,
@@ -39,8 +97,10 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
     double* wsh = y2sh + 4 * rpb;                    // [rpb]
     double* a1sh = wsh + rpb;                        // [rpb]
     double* a2sh = a1sh + rpb;                       // [rpb]
+    static_assert(!RS || U == 8, "the LDS row-sum path reduces 8 rows at a time");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* tile = a2sh + rpb + wave * (8 * 72);     // [4][8*72] private row-sum tiles (RS)
     const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
     const int row0 = rb * rpb, row1 = min(n, row0 + rpb);
     const int col = (pg * 4 + wave) * PW + lane * VN;
@@ -63,15 +123,16 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
     }
     if (wave_has_cols) {
         for (int r = row0; r < row1; r += U) {
-            V x[U], mk[U];
+            V x[U];
+            typename MaskLoad<SX, MBITS>::Raw mk[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rr = r + u;
                 x[u] = XV::zero();
-                mk[u] = XV::zero();
+                mk[u] = MaskLoad<SX, MBITS>::zero();
                 if (rr < row1 && ok) {
                     x[u] = stream_load<NT>(reinterpret_cast<const V*>(E + (i64)rr * ldx + col));
-                    mk[u] = stream_load<true>(reinterpret_cast<const V*>(M + (i64)rr * ldm + col));
+                    mk[u] = MaskLoad<SX, MBITS>::load(M, ldm, Mb, ldb, rr, col);
                 }
             }
             double ys[U], y2s[U];
@@ -86,7 +147,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 }
                 double xe[VN], me[VN];
                 XV::unpack(x[u], xe);
-                XV::unpack(mk[u], me);
+                MaskLoad<SX, MBITS>::expand(mk[u], me);
 #pragma unroll
                 for (int e = 0; e < VN; ++e) {
                     double corr = c1 * b1[e];
@@ -105,9 +166,17 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                     if (DO_Y) { yp = fma(xe[e], tv[e], yp); y2p = fma(me[e], tsq[e], y2p); }
                     if (DO_Z) { zacc[e] = fma(wv, xe[e], zacc[e]); z2acc[e] = fma(wv2, me[e], z2acc[e]); }
                 }
-                if (DO_Y) { ys[u] = wave_sum<double>(yp); y2s[u] = wave_sum<double>(y2p); }
+                if (DO_Y) {
+                    ys[u] = RS ? yp : wave_sum<double>(yp);
+                    y2s[u] = RS ? y2p : wave_sum<double>(y2p);
+                }
             }
-            if (DO_Y) {
+            if constexpr (DO_Y && RS) {
+                const double t1 = wave_rowsum8(reinterpret_cast<const double (&)[8]>(ys), tile, lane);
+                const double t2 = wave_rowsum8(reinterpret_cast<const double (&)[8]>(y2s), tile, lane);
+                const int rr = r + (lane >> 3);
+                if ((lane & 7) == 0 && rr < row1) { ysh[wave * rpb + rr - row0] = t1; y2sh[wave * rpb + rr - row0] = t2; }
+            } else if (DO_Y) {
                 double yv = ys[0], y2v = y2s[0];
 #pragma unroll
                 for (int u = 1; u < U; ++u)

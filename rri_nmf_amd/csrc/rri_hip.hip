@@ -264,8 +264,8 @@ struct LaunchX {
         if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
         if (err != hipSuccess) return RRI_ERR_HIP;
         if (bad) return RRI_OK;
-        c->ldb = (c->LD + 31) / 32;
-        err = hipMalloc((void**)&c->Mbits, (size_t)c->n * c->ldb * sizeof(unsigned));
+        c->ldb = (c->LD + 3) / 4;   // one word per 8 rows x 4 columns
+        err = hipMalloc((void**)&c->Mbits, (size_t)((c->n + 7) / 8) * c->ldb * sizeof(unsigned));
         if (err != hipSuccess) { c->Mbits = nullptr; return RRI_ERR_HIP; }
         hipLaunchKernelGGL((k_mask_pack<SX>), dim3(4096), dim3(256), 0, c->stream, (const SX*)c->M, c->ldm, c->n,
                            c->d, c->Mbits, c->ldb);
@@ -742,7 +742,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
     rpb = std::max<i64>(rpb, rpb_min);
-    rpb = std::min<i64>(round_up(rpb, 16), weighted ? 512 : 1024);   // LDS: 6 (11 weighted) doubles per row
+    // LDS per workgroup = (6 rows-doubles plain | 11 weighted) * rpb + 4 row-sum tiles (18 KiB): keep it under
+    // 40 KiB so that 4 workgroups (16 waves) fit a CU's 160 KiB -- with 62 KiB the weighted passes ran at 2
+    // workgroups per CU and 20 % slower
+    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : 6) * 8)) / 16 * 16;
+    rpb = std::min<i64>(round_up(rpb, 16), rpb_cap);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
     c->nwb = (int)((n + 64 * WCOL_TILES - 1) / (64 * WCOL_TILES));   // k_wcol blocks = rows of Gpart

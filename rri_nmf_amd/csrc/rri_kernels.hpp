@@ -721,7 +721,9 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
                 const i64 j = c0 + tx * 4 + b;
                 if (j >= d) continue;
                 S e = (S)X[i * ldx + j] - acc[a][b];
-                const S m = !MASKED ? S(1) : (Mb ? (S)((Mb[i * ldb + (j >> 5)] >> (j & 31)) & 1u) : (S)M[i * ldm + j]);
+                const S m = !MASKED ? S(1)
+                                    : (Mb ? (S)((Mb[(i >> 3) * ldb + (j >> 2)] >> ((int)((i & 7) << 2) + (int)(j & 3))) & 1u)
+                                          : (S)M[i * ldm + j]);
                 if (WRITE_E) E[i * lde + j] = (SX)(m * e);
                 so[a] += (double)m * (double)e * (double)e;
                 const double ep = e > S(0) ? (double)e : 0.0;

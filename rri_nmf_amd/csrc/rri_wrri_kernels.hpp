@@ -17,8 +17,14 @@
 namespace rri {
 
 // The weights W_mat reach the kernels either as an SX array or, when every entry is 0 or 1 (the recommender
-// case: observed / not observed), bit-packed: row-major, one uint32 per 32 columns.  A lane's VN consecutive
-// columns sit in one word.
+// case: observed / not observed), bit-packed.  Layout of the packed mask: one uint32 per (8 rows x 4 columns):
+//     Mb[(row >> 3) * ldb + (col >> 2)]   bit ((row & 7) * 4 + (col & 3))
+// so the word a lane needs for its 4 (or 2) columns covers the 8 rows it keeps in flight, and the 64 lanes of a
+// wave read 64 consecutive words: ONE coalesced 256-byte load per 8 rows instead of eight 32-byte ones.
+__device__ __forceinline__ unsigned mask_bit(const unsigned* __restrict__ Mb, i64 ldb, i64 row, i64 col) {
+    return (Mb[(row >> 3) * ldb + (col >> 2)] >> (((int)(row & 7) << 2) + (int)(col & 3))) & 1u;
+}
+
 template <typename SX, bool MBITS>
 struct MaskLoad {
     typedef typename XVec<SX>::type V;
@@ -31,7 +37,8 @@ struct MaskLoad {
     }
     static __device__ __forceinline__ Raw load(const SX* __restrict__ M, i64 ldm, const unsigned* __restrict__ Mb,
                                                i64 ldb, i64 row, int col) {
-        if constexpr (MBITS) return Mb[row * ldb + (col >> 5)] >> (col & 31);
+        // bits: the lane's nibble (or half nibble) of row `row`, shifted down to bit 0
+        if constexpr (MBITS) return Mb[(row >> 3) * ldb + (col >> 2)] >> (((int)(row & 7) << 2) + (col & 3));
         else return stream_load<true>(reinterpret_cast<const V*>(M + row * ldm + col));
     }
     static __device__ __forceinline__ void expand(const Raw& r, double (&me)[VN]) {
@@ -58,17 +65,22 @@ __global__ __launch_bounds__(256) void k_mask_nonbinary(const SX* __restrict__ M
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(out, 1);
 }
 
-// Mb[r][w] bit b = (M[r][32 w + b] != 0); columns beyond d are 0
+// packs M into the (8 rows x 4 columns)-per-word layout; rows beyond n and columns beyond d are 0
 template <typename SX>
 __global__ __launch_bounds__(256) void k_mask_pack(const SX* __restrict__ M, i64 ldm, i64 n, i64 d,
                                                    unsigned* __restrict__ Mb, i64 ldb) {
-    const i64 total = n * ldb;
+    const i64 ngroups = (n + 7) >> 3;
+    const i64 total = ngroups * ldb;
     for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-        const i64 r = idx / ldb, w = idx - r * ldb;
+        const i64 rg = idx / ldb, cg = idx - rg * ldb;
         unsigned bits = 0;
-        for (int b = 0; b < 32; ++b) {
-            const i64 c = w * 32 + b;
-            if (c < d && M[r * ldm + c] != SX(0)) bits |= (1u << b);
+        for (int rr = 0; rr < 8; ++rr) {
+            const i64 r = rg * 8 + rr;
+            if (r >= n) break;
+            for (int cc = 0; cc < 4; ++cc) {
+                const i64 c = cg * 4 + cc;
+                if (c < d && M[r * ldm + c] != SX(0)) bits |= (1u << (rr * 4 + cc));
+            }
         }
         Mb[idx] = bits;
     }

@@ -98,6 +98,13 @@ rri_status rri_upload_mask(rri_ctx* ctx, const void* host, int64_t ld, int32_t h
  * row-major with row stride ld (a multiple of 16 bytes, base 16-byte aligned). */
 rri_status rri_bind_X_device(rri_ctx* ctx, const void* dev, int64_t ld);
 rri_status rri_bind_mask_device(rri_ctx* ctx, const void* dev, int64_t ld);
+/* Ingestion without host densification (the reference densifies with .toarray(), sklearn_interface.py:78-102):
+ * X from host CSR arrays (indptr n+1 int64, indices int32 column ids, data of data_dtype) scattered into the
+ * zero-filled dense device X; and the observation mask W_mat = [X != 0] of such a matrix, built bit-packed. */
+rri_status rri_upload_X_csr(rri_ctx* ctx, const int64_t* indptr, const int32_t* indices, const void* data,
+                            int64_t nnz, int32_t data_dtype);
+rri_status rri_upload_mask_csr_pattern(rri_ctx* ctx, const int64_t* indptr, const int32_t* indices,
+                                       const void* data, int64_t nnz, int32_t data_dtype);
 rri_status rri_set_W(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);  /* n*k */
 rri_status rri_set_T(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);  /* k*d */
 rri_status rri_get_W(rri_ctx* ctx, void* host, int64_t ld, int32_t host_dtype);

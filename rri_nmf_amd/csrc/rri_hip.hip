@@ -863,6 +863,90 @@ rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t hos
     return s;
 }
 
+namespace {
+struct CsrDev {   // device copies of the host CSR arrays of one call
+    i64* indptr = nullptr;
+    int* indices = nullptr;
+    void* data = nullptr;
+    ~CsrDev() { (void)hipFree(indptr); (void)hipFree(indices); (void)hipFree(data); }
+};
+rri_status csr_to_device(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data, int64_t nnz,
+                         int32_t data_dtype, CsrDev& out) {
+    if (!indptr || (nnz > 0 && (!indices || !data)) || nnz < 0) return fail(c, RRI_ERR_INVALID, "bad CSR arrays");
+    if (data_dtype != RRI_F32 && data_dtype != RRI_F64) return fail(c, RRI_ERR_INVALID, "bad CSR data dtype");
+    if (indptr[0] != 0 || indptr[c->n] != nnz) return fail(c, RRI_ERR_INVALID, "indptr does not span nnz");
+    for (i64 r = 0; r < c->n; ++r)
+        if (indptr[r + 1] < indptr[r]) return fail(c, RRI_ERR_INVALID, "indptr not monotone at row %lld", r);
+    for (i64 p = 0; p < nnz; ++p)
+        if (indices[p] < 0 || indices[p] >= c->d) return fail(c, RRI_ERR_INVALID, "column index out of range at %lld", p);
+    const size_t ds = data_dtype == RRI_F32 ? 4 : 8;
+    HIPCHK(c, hipMalloc((void**)&out.indptr, (size_t)(c->n + 1) * sizeof(i64)));
+    HIPCHK(c, hipMalloc((void**)&out.indices, (size_t)std::max<i64>(nnz, 1) * sizeof(int)));
+    HIPCHK(c, hipMalloc(&out.data, (size_t)std::max<i64>(nnz, 1) * ds));
+    HIPCHK(c, hipMemcpyAsync(out.indptr, indptr, (size_t)(c->n + 1) * sizeof(i64), hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) {
+        HIPCHK(c, hipMemcpyAsync(out.indices, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out.data, data, (size_t)nnz * ds, hipMemcpyHostToDevice, c->stream));
+    }
+    return RRI_OK;
+}
+}  // namespace
+
+rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
+                            int64_t nnz, int32_t data_dtype) {
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    CsrDev dv;
+    rri_status s = csr_to_device(c, indptr, indices, data, nnz, data_dtype, dv);
+    if (s != RRI_OK) return s;
+    if (c->X && !c->own_X) c->X = nullptr;
+    if (!c->X) {
+        HIPCHK(c, hipMalloc(&c->X, (size_t)c->n * c->LD * c->es));
+        c->own_X = true;
+    }
+    c->ldx = c->LD;
+    HIPCHK(c, hipMemsetAsync(c->X, 0, (size_t)c->n * c->LD * c->es, c->stream));
+    const unsigned nb = (unsigned)((c->n + 3) / 4);
+    if (c->dtype == RRI_F32) {
+        if (data_dtype == RRI_F32) hipLaunchKernelGGL((k_csr_scatter<float, float>), dim3(nb), dim3(256), 0, c->stream, dv.indptr, dv.indices, (const float*)dv.data, c->n, (float*)c->X, c->ldx);
+        else hipLaunchKernelGGL((k_csr_scatter<double, float>), dim3(nb), dim3(256), 0, c->stream, dv.indptr, dv.indices, (const double*)dv.data, c->n, (float*)c->X, c->ldx);
+    } else {
+        if (data_dtype == RRI_F32) hipLaunchKernelGGL((k_csr_scatter<float, double>), dim3(nb), dim3(256), 0, c->stream, dv.indptr, dv.indices, (const float*)dv.data, c->n, (double*)c->X, c->ldx);
+        else hipLaunchKernelGGL((k_csr_scatter<double, double>), dim3(nb), dim3(256), 0, c->stream, dv.indptr, dv.indices, (const double*)dv.data, c->n, (double*)c->X, c->ldx);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_X = true;
+    invalidate(c);
+    c->q_valid = false;
+    return RRI_OK;
+}
+
+rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
+                                       int64_t nnz, int32_t data_dtype) {
+    CHECK_CTX(c);
+    if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
+    HIPCHK(c, hipSetDevice(c->device));
+    CsrDev dv;
+    rri_status s = csr_to_device(c, indptr, indices, data, nnz, data_dtype, dv);
+    if (s != RRI_OK) return s;
+    if (c->M && c->own_M) (void)hipFree(c->M);
+    c->M = nullptr;
+    c->own_M = false;
+    c->ldm = c->LD;
+    if (c->Mbits) { (void)hipFree(c->Mbits); c->Mbits = nullptr; }
+    c->ldb = (c->LD + 3) / 4;
+    const size_t words = (size_t)((c->n + 7) / 8) * c->ldb;
+    HIPCHK(c, hipMalloc((void**)&c->Mbits, words * sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(c->Mbits, 0, words * sizeof(unsigned), c->stream));
+    const unsigned nb = (unsigned)((c->n + 3) / 4);
+    if (data_dtype == RRI_F32) hipLaunchKernelGGL((k_csr_pattern_bits<float>), dim3(nb), dim3(256), 0, c->stream, dv.indptr, dv.indices, (const float*)dv.data, c->n, c->Mbits, c->ldb);
+    else hipLaunchKernelGGL((k_csr_pattern_bits<double>), dim3(nb), dim3(256), 0, c->stream, dv.indptr, dv.indices, (const double*)dv.data, c->n, c->Mbits, c->ldb);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_M = true;
+    invalidate(c);
+    return RRI_OK;
+}
+
 rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)

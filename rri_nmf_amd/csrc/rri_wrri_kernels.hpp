@@ -86,6 +86,29 @@ __global__ __launch_bounds__(256) void k_mask_pack(const SX* __restrict__ M, i64
     }
 }
 
+// CSR row -> dense row (one wave per row): X[r, indices[p]] = data[p]
+template <typename DT, typename SX>
+__global__ __launch_bounds__(256) void k_csr_scatter(const i64* __restrict__ indptr, const int* __restrict__ indices,
+                                                     const DT* __restrict__ data, i64 n, SX* __restrict__ X, i64 ldx) {
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    for (i64 p = indptr[r] + (threadIdx.x & 63); p < indptr[r + 1]; p += 64) X[r * ldx + indices[p]] = (SX)data[p];
+}
+// observation bits of a CSR matrix: bit (r, indices[p]) = 1 where data[p] != 0
+template <typename DT>
+__global__ __launch_bounds__(256) void k_csr_pattern_bits(const i64* __restrict__ indptr, const int* __restrict__ indices,
+                                                          const DT* __restrict__ data, i64 n, unsigned* __restrict__ Mb,
+                                                          i64 ldb) {
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    for (i64 p = indptr[r] + (threadIdx.x & 63); p < indptr[r + 1]; p += 64) {
+        if (data[p] != DT(0)) {
+            const int c = indices[p];
+            atomicOr(&Mb[(r >> 3) * ldb + (c >> 2)], 1u << (((int)(r & 7) << 2) + (c & 3)));
+        }
+    }
+}
+
 // Same block geometry as k_pass: 4 waves = 4 adjacent 1 KiB-wide panels x one row block.
 //   e' = e - m (a1_i b1_j + [UPD2] a2_i b2_j)      (a1,a2: per row, from LDS; b1,b2: per column, registers)
 //   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , Z2part = sum_i w_i^2 m

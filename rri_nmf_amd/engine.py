@@ -99,6 +99,30 @@ class RRIEngine(object):
             raise ValueError('W_mat has wrong dimensions')
         self._check(self._lib.rri_upload_mask(self._h, M.ctypes.data, M.strides[0] // M.itemsize, _NP2RRI[M.dtype]))
 
+    def _csr_args(self, A):
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        if A.shape != (self.n, self.d):
+            raise ValueError('sparse matrix has wrong dimensions')
+        A.sum_duplicates()
+        data = A.data if A.data.dtype in _NP2RRI else A.data.astype(np.float64)
+        indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+        data = np.ascontiguousarray(data)
+        keep = (indptr, indices, data)   # alive for the duration of the call
+        return keep, (indptr.ctypes.data_as(C.POINTER(C.c_int64)), indices.ctypes.data_as(C.POINTER(C.c_int32)),
+                      data.ctypes.data, int(A.nnz), _NP2RRI[data.dtype])
+
+    def upload_X_csr(self, A):
+        """X from a scipy sparse matrix, densified on the device (no host .toarray())"""
+        keep, args = self._csr_args(A)
+        self._check(self._lib.rri_upload_X_csr(self._h, *args))
+
+    def upload_mask_csr_pattern(self, A):
+        """W_mat = [A != 0] of a scipy sparse matrix, bit-packed on the device"""
+        keep, args = self._csr_args(A)
+        self._check(self._lib.rri_upload_mask_csr_pattern(self._h, *args))
+
     def bind_X_device(self, ptr, ld):
         self._check(self._lib.rri_bind_X_device(self._h, C.c_void_p(ptr), int(ld)))
 

@@ -23,6 +23,7 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, row_
     """W (n x k), H (k x d) >= 0.  'random' | 'smart_random' | 'nndsvd' | 'nndsvda' | 'nndsvdar'."""
     n, d = X.shape
     k = n_components
+    # X may be a scipy sparse matrix: randomized_svd and .mean() take it as it is
     if init is None:
         init = 'nndsvd' if k < d else 'random'
     if init == 'random':                      # initialization.py:80-87 (T drawn first)

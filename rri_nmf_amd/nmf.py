@@ -52,15 +52,36 @@ class TrueObjComputer(object):
         k = self.W.shape[1]
         with RRIEngine(n, d, k, dtype=_storage_dtype(X, self._dtype), weighted=self.Wm is not None,
                        device=self._device) as eng:
-            eng.upload_X(X)
-            if self.Wm is not None:
-                eng.upload_mask(self.Wm)
+            _upload_problem(eng, X, self.Wm)
             eng.set_W(self.W)
             eng.set_T(self.T)
             eng.set_params(reg_w_l1=self.reg_w_l1, reg_w_l2=self.reg_w_l2, reg_t_l1=self.reg_t_l1,
                            reg_t_l2=self.reg_t_l2)
             self.obj = eng.objective()
         return self.obj
+
+
+def _upload_problem(eng, X, W_mat):
+    """X and the weights to the device.  scipy sparse inputs go up as CSR and are densified / bit-packed there
+    (SURVEY.md 8f rank 3); dense inputs as they are."""
+    if scipy.sparse.issparse(X):
+        eng.upload_X_csr(X)
+    else:
+        eng.upload_X(X)
+    if W_mat is not None:
+        if scipy.sparse.issparse(W_mat):
+            eng.upload_mask_csr_pattern(W_mat)
+        else:
+            eng.upload_mask(W_mat)
+
+
+def _sparse_mask_or_dense(W_mat):
+    """a scipy sparse W_mat stays sparse only when it is an observation pattern (all stored values 1)"""
+    if W_mat is None or not scipy.sparse.issparse(W_mat):
+        return W_mat
+    W_mat = W_mat.tocsr()
+    W_mat.eliminate_zeros()
+    return W_mat if np.all(W_mat.data == 1) else W_mat.toarray()
 
 
 def _storage_dtype(X, dtype):
@@ -79,7 +100,12 @@ def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, projec
     override, clamp at 0 (copies: the caller's arrays are never written), project when the
     constraints are kept every sweep."""
     if _is_empty(W_in) or _is_empty(T_in):
-        src = X if W_mat is None else W_mat * X
+        if W_mat is None:
+            src = X
+        elif scipy.sparse.issparse(W_mat) or scipy.sparse.issparse(X):
+            src = scipy.sparse.csr_matrix(W_mat).multiply(X).tocsr()
+        else:
+            src = W_mat * X
         W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False)
         if t_row_sum is not None:
             T = normalize(T) * t_row_sum
@@ -132,9 +158,12 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if eps_gauss_t or delta_gauss_t:
         raise NotImplementedError('the Gaussian mechanism (eps_gauss_t/delta_gauss_t) is not available '
                                   'on the device path (SURVEY.md section 8f rank 4)')
+    # scipy sparse X / 0-1 sparse W_mat are ingested as CSR (no host densification); row weights need a dense X
     if scipy.sparse.issparse(X):
-        X = X.toarray()
-    X = np.asarray(X)
+        X = X.tocsr() if w_row is None else X.toarray()
+    else:
+        X = np.asarray(X)
+    W_mat = _sparse_mask_or_dense(W_mat)
     rtv = {}
     n, d = X.shape
 
@@ -188,9 +217,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     sdt = _storage_dtype(X, dtype)
     eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device)
     try:
-        eng.upload_X(X)
-        if W_mat is not None:
-            eng.upload_mask(W_mat)
+        _upload_problem(eng, X, W_mat)
         eng.set_W(W)
         eng.set_T(T)
         eng.set_params(fix_W=fix_W, fix_T=fix_T, project_T_each_iter=project_T_each_iter,
@@ -215,8 +242,12 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         for iter_no in range(max_iter):
             if early_stop:                       # nmf.py:381-407
                 if callable(early_stop):
-                    Wh, Th = current()
-                    this_score = early_stop(X, Wh, Th)
+                    entries = getattr(early_stop, 'device_entries', None)
+                    if entries is not None:   # clipped RMSE on listed entries: evaluated on the device
+                        this_score = eng.masked_rmse(*entries)
+                    else:
+                        Wh, Th = current()
+                        this_score = early_stop(X, Wh, Th)
                 elif compute_obj_each_iter:
                     this_score = np.inf if not obj_history else obj_history[-1]
                 logger.info('Iter %d stopping score %.3f' % (iter_no, this_score))

@@ -81,6 +81,9 @@ class NMF_RS_Estimator(_FactorPair, sklearn.base.BaseEstimator):
                 pred = np.clip(np.dot(W, T), lo, hi)
                 return np.sqrt(np.mean((pred[vi, vj] - Xv[vi, vj]) ** 2))
 
+            # same score without bringing W, T to the host and forming the n x d product there: nmf() evaluates
+            # callbacks that carry `device_entries` with rri_masked_rmse on the device
+            RMSE_val.device_entries = (vi, vj, Xv[vi, vj], lo, hi)
             self.early_stop = RMSE_val
         else:
             self.early_stop = False

@@ -261,3 +261,36 @@ def test_sharded_resets_match_single_call_path():
             assert relfro(Wb, Wa) < 1e-12 and relfro(Tb, Ta) < 1e-12
     finally:
         dist.destroy_process_group()
+
+
+def test_sparse_inputs_are_ingested_as_csr():
+    """scipy sparse X and a sparse 0/1 W_mat give what their dense forms give (same start passed in)"""
+    import scipy.sparse as sp
+    nmf_mod, _ = api()
+    from rri_nmf_amd.engine import RRIEngine
+    g = load_golden('g4_wrri')
+    X = g['X'].astype(np.float64)
+    Xs = sp.csr_matrix(X)
+    Wm = np.zeros(X.shape)
+    Wm[X.nonzero()] = 1.0
+    p = dict(max_iter=5, eps_stop=-1, W_in=g['W0'], T_in=g['T0'], reset_topic_method=None, t_row_sum=1.0)
+    a = nmf_mod.nmf(X, 7, W_mat=Wm, **p)
+    b = nmf_mod.nmf(Xs, 7, W_mat=sp.csr_matrix(Wm), **p)
+    assert np.array_equal(a['W'], b['W']) and np.array_equal(a['T'], b['T'])
+    assert np.allclose(a['obj_history'], b['obj_history'], rtol=1e-13)
+    # unweighted, float32 storage, ragged shape; and own NNDSVD start from the sparse matrix
+    rs = np.random.RandomState(0)
+    D = (rs.rand(333, 129) < 0.07) * rs.rand(333, 129)
+    W0, T0 = scaled_init(D + 0.01, 4, seed=3)
+    a = nmf_mod.nmf(D.astype(np.float32), 4, W_in=W0, T_in=T0, max_iter=3, eps_stop=-1)
+    b = nmf_mod.nmf(sp.csr_matrix(D.astype(np.float32)), 4, W_in=W0, T_in=T0, max_iter=3, eps_stop=-1)
+    assert np.array_equal(a['W'], b['W']) and np.array_equal(a['T'], b['T'])
+    c = nmf_mod.nmf(sp.csr_matrix(D), 4, max_iter=3, random_state=0)
+    assert c['W'].shape == (333, 4) and np.isfinite(c['W']).all() and c['obj_history'][-1] <= c['obj_history'][0]
+    # engine level: malformed CSR is rejected before anything is launched
+    with RRIEngine(333, 129, 4) as e:
+        bad = sp.csr_matrix(D)
+        bad.indices = bad.indices.copy()
+        bad.indices[0] = 500
+        with pytest.raises(ValueError, match='column index'):
+            e.upload_X_csr(bad)

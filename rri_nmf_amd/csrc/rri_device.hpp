@@ -1,7 +1,8 @@
 // rri_device.hpp -- device-side helpers shared by the RRI kernels (gfx950 / CDNA4 only).
 //
-// Wave = 64 lanes.  Cross-lane sums use DPP modifiers (one VALU op per step, no LDS
-// crossbar traffic); workgroup sums go wave -> LDS -> wave.
+// Wave = 64 lanes.  Cross-lane sums use DPP modifiers (one VALU op per step, no LDS crossbar
+// traffic) or, for 8 rows at once, a wave-private LDS tile; workgroup sums go wave -> LDS -> wave.
+// All reductions are in float64 and in a fixed order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,48 +10,6 @@
 namespace rri {
 
 typedef long long i64;
-
-// ---- 16-byte vector of the arithmetic type ------------------------------------------
-template <typename S> struct V16;
-template <> struct V16<float> {
-    typedef float4 type;
-    static constexpr int N = 4;
-};
-template <> struct V16<double> {
-    typedef double2 type;
-    static constexpr int N = 2;
-};
-
-__device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
-__device__ __forceinline__ float vdot(const float4& a, const float4& b, float acc) {
-    acc = fmaf(a.x, b.x, acc);
-    acc = fmaf(a.y, b.y, acc);
-    acc = fmaf(a.z, b.z, acc);
-    acc = fmaf(a.w, b.w, acc);
-    return acc;
-}
-__device__ __forceinline__ double vdot(const double2& a, const double2& b, double acc) {
-    acc = fma(a.x, b.x, acc);
-    acc = fma(a.y, b.y, acc);
-    return acc;
-}
-__device__ __forceinline__ void vaxpy(float4& z, float w, const float4& x) {
-    z.x = fmaf(w, x.x, z.x);
-    z.y = fmaf(w, x.y, z.y);
-    z.z = fmaf(w, x.z, z.z);
-    z.w = fmaf(w, x.w, z.w);
-}
-__device__ __forceinline__ void vaxpy(double2& z, double w, const double2& x) {
-    z.x = fma(w, x.x, z.x);
-    z.y = fma(w, x.y, z.y);
-}
-__device__ __forceinline__ void vadd(float4& z, const float4& x) {
-    z.x += x.x; z.y += x.y; z.z += x.z; z.w += x.w;
-}
-__device__ __forceinline__ void vadd(double2& z, const double2& x) {
-    z.x += x.x; z.y += x.y;
-}
 
 // ---- DPP lane moves -------------------------------------------------------------------
 // dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141,
@@ -60,17 +19,10 @@ __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp(float v) {
-    return __int_as_float(dpp_i32<CTRL, ROW_MASK>(__float_as_int(v)));
-}
-template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp(double v) {
     int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
     int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
     return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float lane_get(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ __forceinline__ double lane_get(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -90,11 +42,6 @@ __device__ __forceinline__ S wave_sum(S v) {
     v += dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
     return lane_get(v, 63);
 }
-__device__ __forceinline__ i64 wave_sum_i64(i64 v) {
-    double d = wave_sum<double>((double)v);  // counts < 2^53: exact
-    return (i64)d;
-}
-
 // Sums of 8 rows at once: v[u] is this lane's partial of row u (u < 8).  The wave parks the 8 x 64 partials in
 // a PRIVATE LDS tile (8 rows x 72 doubles, padded), re-reads them transposed -- lane = (row r = lane>>3,
 // part p = lane&7) adds the 8 partials p*8..p*8+7 of row r -- and three DPP steps add the 8 parts.  Returns

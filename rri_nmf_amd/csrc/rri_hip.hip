@@ -32,7 +32,14 @@ using namespace rri;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;   // text of the last failed rri_create of this thread
+
+// temporary device buffer that is released on every return path
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
 
 struct Cursor {
     int sweep, topic, phase;  // phase 0 = T-row half, 1 = W-column half
@@ -1157,14 +1164,15 @@ rri_status rri_project_W_rows(rri_ctx* c, double s, const double* s_vec) {
     if (!c->have_W) return fail(c, RRI_ERR_INVALID, "W not set");
     if (!s_vec && !(s > 0)) return fail(c, RRI_ERR_INVALID, "Radius s must be strictly positive");
     HIPCHK(c, hipSetDevice(c->device));
+    DevTmp dv;
     double* dvec = nullptr;
     if (s_vec) {
-        HIPCHK(c, hipMalloc((void**)&dvec, (size_t)c->n * sizeof(double)));
+        HIPCHK(c, dv.alloc((size_t)c->n * sizeof(double)));
+        dvec = (double*)dv.p;
         HIPCHK(c, hipMemcpyAsync(dvec, s_vec, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     LK::proj_rows(c, s, dvec);
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (dvec) (void)hipFree(dvec);
     invalidate(c);
     if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "projection failed: %s", hipGetErrorString(e));
     return RRI_OK;
@@ -1221,12 +1229,12 @@ rri_status rri_argmax_rows(rri_ctx* c, int32_t* out_host) {
     CHECK_CTX(c);
     if (!out_host) return fail(c, RRI_ERR_INVALID, "out is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    int* dev = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dev, (size_t)c->n * sizeof(int)));
+    DevTmp dv;
+    HIPCHK(c, dv.alloc((size_t)c->n * sizeof(int)));
+    int* dev = (int*)dv.p;
     LK::argmax_rows(c, dev);
     hipError_t e = hipMemcpyAsync(out_host, dev, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dev);
     if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "argmax failed: %s", hipGetErrorString(e));
     return RRI_OK;
 }

@@ -47,7 +47,7 @@ class TrueObjComputer(object):
         self._dtype, self._device = dtype, device
 
     def true_objective(self):
-        X = self.X if self.wr is None else self.X  # w_row is already folded into X by nmf()
+        X = self.X   # row weights, when used, are already folded into X by nmf() (nmf.py:335-338)
         n, d = X.shape
         k = self.W.shape[1]
         with RRIEngine(n, d, k, dtype=_storage_dtype(X, self._dtype), weighted=self.Wm is not None,
@@ -225,8 +225,6 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
                        n_resets=n_resets, reg_w_l1=reg_w_l1, reg_w_l2=reg_w_l2, reg_t_l1=reg_t_l1,
                        reg_t_l2=reg_t_l2, fix_reset_seed=fix_reset_seed)
 
-        host_views = bool(diagnostics) or callable(early_stop)
-
         def current():
             return eng.get_W(), eng.get_T()
 
@@ -235,7 +233,6 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
 
         iter_cputime, obj_history = [], []
         last_score = np.inf
-        rolled_back = False
         if early_stop:
             eng.snapshot()
 
@@ -253,7 +250,6 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
                 logger.info('Iter %d stopping score %.3f' % (iter_no, this_score))
                 if this_score > last_score:
                     eng.rollback()
-                    rolled_back = True
                     obj_history = obj_history[:-1]
                     iter_cputime = iter_cputime[:-1]
                     for f in diagnostics:
@@ -293,7 +289,6 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         n_resets_used = eng.n_resets_used
     finally:
         eng.close()
-    del host_views, rolled_back
 
     if w_row is not None:                        # nmf.py:531-539: refit W on the unweighted rows
         sub = nmf(X_orig, k, T_in=T, fix_T=True, max_iter=10, w_row_sum=w_row_sum,

@@ -178,7 +178,8 @@ def main():
     eng.set_T(T0)
     flags = dict(t_row_sum=1.0, reset_topic_method=None) if weighted else {}
     eng.set_params(**flags)   # plain RRI: no constraints, default resets; WRRI: the RS-fit flags
-    drv = ShardedRRI(eng, red, k, stream=stream) if sharded else None
+    row_lo = rank * n_local if cfg['scaling'] == 'weak' else shard_rows(cfg['n'], world, rank)[0]
+    drv = ShardedRRI(eng, red, k, stream=stream, row_lo=row_lo, n_global=n_global) if sharded else None
 
     def run(steps):
         if drv is None:

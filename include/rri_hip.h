@@ -148,6 +148,12 @@ rri_status rri_masked_rmse(rri_ctx* ctx, const int64_t* ij, const double* vals, 
 rri_status rri_snapshot(rri_ctx* ctx);
 rri_status rri_rollback(rri_ctx* ctx);
 
+/* Products with the resident X for the initialisation (randomized SVD behind NNDSVD, initialization.py:105;
+ * SURVEY 8f rank 2): out = X B (B: d x m host row-major, out: n x m) and out = X^T Q (Q: n x m, out: d x m),
+ * float64 arithmetic on the stored X.  Blocking; not part of the sweep path. */
+rri_status rri_X_times(rri_ctx* ctx, const double* B, int32_t m, double* out);
+rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
+
 /* ---- row-sharded multi-GPU (one process per GPU; the caller owns the collective) ---- */
 /* A topic step splits at the one cross-row reduction it needs.  rri_topic_reduce_local
  * leaves this rank's partial sums [w_t^T X (d) | w_t^T W (k) | ||w_t||^2 | sum W[:,t-1] | pad]

@@ -67,6 +67,8 @@ PROTOTYPES = {
     'rri_masked_rmse': (_I32, [_P, C.POINTER(_I64), C.POINTER(_D), _I64, _D, _D, C.POINTER(_D)]),
     'rri_snapshot': (_I32, [_P]),
     'rri_rollback': (_I32, [_P]),
+    'rri_X_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
+    'rri_Xt_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
     'rri_reduce_buffer': (_I32, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     'rri_bind_reduce_buffer': (_I32, [_P, _P, _I64]),
     'rri_topic_reduce_local': (_I32, [_P, _I32]),

@@ -279,9 +279,17 @@ struct LaunchX {
         err = hipStreamSynchronize(c->stream);
         return err == hipSuccess ? RRI_OK : RRI_ERR_HIP;
     }
-    static void xtt(rri_ctx* c) {
+    static void xtt_any(rri_ctx* c, const double* Tm, int m, double* out) {   // out (m x n) = (X Tm^T)^T
         hipLaunchKernelGGL((k_xtt<SX>), dim3((unsigned)((c->n + 63) / 64)), dim3(256), 0, c->stream, (const SX*)c->X,
-                           c->ldx, (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, c->Qt, c->ldw);
+                           c->ldx, Tm, c->LD, (int)c->n, (int)c->d, m, out, c->ldw);
+    }
+    static void xtt(rri_ctx* c) { xtt_any(c, c->T, c->k, c->Qt); }
+    // column sums of X against an arbitrary n-vector (device): leaves them in red[0..LD)
+    static void colsums(rri_ctx* c, const double* wvec) {
+        pass_cfg<false, true, false>(c, c->X, c->T, wvec, nullptr, nullptr);
+        const int nb = (int)((c->LD + 31) / 32);
+        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
+                           (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
     }
     static size_t resid_shmem(const rri_ctx* c) {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
@@ -1289,6 +1297,48 @@ rri_status rri_rollback(rri_ctx* c) {
     c->q_valid = false;
     c->pending_wcheck = false;
     return RRI_OK;
+}
+
+// ---- products with X for the initialisation -------------------------------------------------------------------
+rri_status rri_X_times(rri_ctx* c, const double* B, int32_t m, double* out) {
+    CHECK_CTX(c);
+    if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
+    if (!B || !out || m < 1) return fail(c, RRI_ERR_INVALID, "bad operand");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevTmp tm, outm;
+    HIPCHK(c, tm.alloc((size_t)m * c->LD * sizeof(double)));      // B^T as an m x LD "T-like" operand
+    HIPCHK(c, outm.alloc((size_t)m * c->ldw * sizeof(double)));   // (X B)^T, m x n
+    HIPCHK(c, hipMemsetAsync(tm.p, 0, (size_t)m * c->LD * sizeof(double), c->stream));
+    rri_status s = to_device(c, B, m, RRI_F64, tm.p, c->LD, c->d, m, RRI_F64, true);
+    if (s != RRI_OK) return s;
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    DISPATCH(c, L::xtt_any(c, (const double*)tm.p, m, (double*)outm.p));
+    return to_host(c, outm.p, c->ldw, out, m, RRI_F64, c->n, m, RRI_F64, true);
+}
+
+rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
+    CHECK_CTX(c);
+    if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
+    if (!Q || !out || m < 1) return fail(c, RRI_ERR_INVALID, "bad operand");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevTmp qm, outm;
+    HIPCHK(c, qm.alloc((size_t)m * c->ldw * sizeof(double)));     // Q^T, m x n: every column contiguous
+    HIPCHK(c, outm.alloc((size_t)m * c->LD * sizeof(double)));    // (X^T Q)^T, m x LD
+    rri_status s = to_device(c, Q, m, RRI_F64, qm.p, c->ldw, c->n, m, RRI_F64, true);
+    if (s != RRI_OK) return s;
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    const bool tm_on = c->timing != 0;
+    const int tsave = c->timing;
+    c->timing = 0;
+    for (int l = 0; l < m; ++l) {
+        DISPATCH(c, L::colsums(c, (const double*)qm.p + (i64)l * c->ldw));
+        HIPCHK(c, hipMemcpyAsync((double*)outm.p + (i64)l * c->LD, c->red, (size_t)c->LD * sizeof(double),
+                                 hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->timing = tsave;
+    (void)tm_on;
+    invalidate(c);   // Zpart / red were used as scratch
+    return to_host(c, outm.p, c->LD, out, m, RRI_F64, c->d, m, RRI_F64, true);
 }
 
 // ---- row-sharded multi-GPU ---------------------------------------------------------------------------------

@@ -270,6 +270,27 @@ class RRIEngine(object):
     def rollback(self):
         self._check(self._lib.rri_rollback(self._h))
 
+    # ---- products with the resident X (initialisation) ----------------------------------------
+    def X_times(self, B):
+        """X @ B for a host (d, m) matrix, float64"""
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        if B.ndim != 2 or B.shape[0] != self.d:
+            raise ValueError('operand must be (d, m)')
+        out = np.empty((self.n, B.shape[1]))
+        self._check(self._lib.rri_X_times(self._h, B.ctypes.data_as(C.POINTER(C.c_double)), B.shape[1],
+                                          out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def Xt_times(self, Q):
+        """X.T @ Q for a host (n, m) matrix, float64"""
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        if Q.ndim != 2 or Q.shape[0] != self.n:
+            raise ValueError('operand must be (n, m)')
+        out = np.empty((self.d, Q.shape[1]))
+        self._check(self._lib.rri_Xt_times(self._h, Q.ctypes.data_as(C.POINTER(C.c_double)), Q.shape[1],
+                                           out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     # ---- row-sharded stepping -----------------------------------------------------------
     def reduce_buffer(self):
         ptr, cnt = C.c_void_p(), C.c_int64()

@@ -14,13 +14,55 @@ from .matrixops import normalize
 _KNOWN = (None, 'random', 'smart_random', 'nndsvd', 'nndsvda', 'nndsvdar')
 
 
+def randomized_svd_device(engine, n_components, random_state=None, n_oversamples=10, n_iter='auto'):
+    """Truncated SVD of the X resident in `engine`, by the algorithm of sklearn.utils.extmath.randomized_svd with
+    its default settings (Halko et al.: Gaussian test matrix, LU-normalised power iterations, one QR, SVD of the
+    small projected matrix, deterministic sign flip) -- the two products with X, which are all of the work, run
+    on the device (rri_X_times / rri_Xt_times, float64); the (n or d) x (k+10) factorisations stay in scipy.
+
+    Follows sklearn step by step so that it returns the same U, S, V up to rounding: the random test matrix is
+    drawn from the same numpy RandomState, the matrix is transposed when n < d, signs are fixed as svd_flip does.
+    """
+    from scipy import linalg
+    n, d = engine.n, engine.d
+    rng = check_random_state(random_state)
+    m = n_components + n_oversamples
+    if n_iter == 'auto':
+        n_iter = 7 if n_components < 0.1 * min(n, d) else 4
+    transpose = n < d                      # work on the matrix with the smaller second dimension
+    A = engine.Xt_times if transpose else engine.X_times       # Q -> A @ Q
+    At = engine.X_times if transpose else engine.Xt_times      # Q -> A.T @ Q
+    Q = rng.normal(size=(n if transpose else d, m))
+    lu = lambda Y: linalg.lu(Y, permute_l=True, check_finite=False)[0]
+    normalize_q = lu if n_iter > 2 else (lambda Y: Y)
+    for _ in range(n_iter):
+        Q = normalize_q(A(Q))
+        Q = normalize_q(At(Q))
+    Q, _ = linalg.qr(A(Q), mode='economic', check_finite=False)
+    B = At(Q).T                            # Q.T @ A
+    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver='gesdd')
+    U = Q @ Uhat
+    if not transpose:                      # svd_flip(U, Vt): the largest |entry| of every column of U is positive
+        signs = np.sign(U[np.argmax(np.abs(U), axis=0), np.arange(U.shape[1])])
+    else:                                  # svd_flip(U, Vt, u_based_decision=False)
+        signs = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+    U = U * signs[np.newaxis, :]
+    Vt = Vt * signs[:, np.newaxis]
+    k = n_components
+    if transpose:
+        return Vt[:k, :].T, s[:k], U[:, :k].T
+    return U[:, :k], s[:k], Vt[:k, :]
+
+
 def _split_pos_neg(v):
     return np.maximum(v, 0), np.abs(np.minimum(v, 0))
 
 
 def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, row_normalize=False,
-                   n_words_beam=20):
-    """W (n x k), H (k x d) >= 0.  'random' | 'smart_random' | 'nndsvd' | 'nndsvda' | 'nndsvdar'."""
+                   n_words_beam=20, engine=None):
+    """W (n x k), H (k x d) >= 0.  'random' | 'smart_random' | 'nndsvd' | 'nndsvda' | 'nndsvdar'.
+    engine: an RRIEngine that already holds X -- the SVD behind the NNDSVD variants then runs its products
+    with X on the device (randomized_svd_device); None = scikit-learn on the host, as the reference."""
     n, d = X.shape
     k = n_components
     # X may be a scipy sparse matrix: randomized_svd and .mean() take it as it is
@@ -41,7 +83,10 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, row_
         # the reference runs the SVD first and raises afterwards (initialization.py:153-157)
         raise ValueError('Invalid init parameter: got %r instead of one of %r' % (init, _KNOWN[:1] + _KNOWN[3:]))
 
-    U, S, V = randomized_svd(X, k, random_state=random_state)
+    if engine is not None:
+        U, S, V = randomized_svd_device(engine, k, random_state=random_state)
+    else:
+        U, S, V = randomized_svd(X, k, random_state=random_state)
     W, H = np.zeros(U.shape), np.zeros(V.shape)
     W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])         # leading pair is sign-definite (:109-111)
     H[0, :] = np.sqrt(S[0]) * np.abs(V[0, :])

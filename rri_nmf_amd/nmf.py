@@ -6,6 +6,9 @@ additions select the device side:
     dtype   storage type of X (and the mask) in HBM: float32 or float64.  None = float32 when X is
             float32, else float64.  The arithmetic is float64 either way (see csrc/rri_kernels.hpp).
     device  HIP device ordinal.
+    device_init  True / False: run the products of the randomized SVD behind the NNDSVD initialisations on the
+            device (initialization.randomized_svd_device) or in scikit-learn on the host; None = on the device from
+            2e7 entries of X on.  Same algorithm either way.
 
 What runs where
     host (numpy, once):   argument checks, warnings and sentinel returns (nmf.py:280-315), the
@@ -94,8 +97,11 @@ def _is_empty(a):
     return int(np.prod(np.shape(a))) == 0
 
 
+DEVICE_INIT_MIN_ELEMS = 2e7   # from this many entries of X on, the SVD behind NNDSVD uses the device products
+
+
 def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, project_T_each_iter,
-                             project_W_each_iter, w_row_sum, t_row_sum, fix_W, fix_T, n, d, **_):
+                             project_W_each_iter, w_row_sum, t_row_sum, fix_W, fix_T, n, d, engine=None, **_):
     """Starting W, T (nmf.py:819-880): initialise BOTH when either input is empty, let W_in / T_in
     override, clamp at 0 (copies: the caller's arrays are never written), project when the
     constraints are kept every sweep."""
@@ -106,7 +112,8 @@ def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, projec
             src = scipy.sparse.csr_matrix(W_mat).multiply(X).tocsr()
         else:
             src = W_mat * X
-        W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False)
+        W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False,
+                              engine=engine if W_mat is None else None)
         if t_row_sum is not None:
             T = normalize(T) * t_row_sum
         if w_row_sum is not None:
@@ -147,7 +154,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0,
         diagnostics=[], store_gradients=False,
         ind_rows_to_store=None, eps_gauss_t=None, delta_gauss_t=None,
-        *, dtype=None, device=0):
+        *, dtype=None, device=0, device_init=None):
     """Non-negative factorisation X ~ W T by rank-one residue iteration; see the module docstring and
     the reference's docstring (nmf.py:109-269) for the parameters.  Returns a dict with 'W', 'T',
     'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
@@ -207,17 +214,24 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         init = 'random'
 
     clock0 = time.perf_counter()
-    W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X, k=k, init=init,
-                                    random_state=random_state, project_T_each_iter=project_T_each_iter,
-                                    project_W_each_iter=project_W_each_iter, w_row_sum=w_row_sum,
-                                    t_row_sum=t_row_sum, fix_W=fix_W, fix_T=fix_T, n=n, d=d)
     if logger.level <= logging.DEBUG:           # nmf.py:366-367 (see the note at the logger)
         compute_obj_each_iter = True
 
     sdt = _storage_dtype(X, dtype)
+    needs_init = _is_empty(W_in) or _is_empty(T_in)
+    if not _is_empty(W_in) and np.shape(W_in) != (n, k):       # shape errors before any device work (nmf.py:853-860)
+        raise ValueError('W_in has wrong dimensions, must be n*k')
+    if not _is_empty(T_in) and np.shape(T_in) != (k, d):
+        raise ValueError('T_in has wrong dimensions, must be k*d')
     eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device)
     try:
         _upload_problem(eng, X, W_mat)
+        on_device = device_init if device_init is not None else (float(n) * d >= DEVICE_INIT_MIN_ELEMS)
+        W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X, k=k, init=init,
+                                        random_state=random_state, project_T_each_iter=project_T_each_iter,
+                                        project_W_each_iter=project_W_each_iter, w_row_sum=w_row_sum,
+                                        t_row_sum=t_row_sum, fix_W=fix_W, fix_T=fix_T, n=n, d=d,
+                                        engine=eng if (on_device and needs_init and init not in ('random', 'smart_random')) else None)
         eng.set_W(W)
         eng.set_T(T)
         eng.set_params(fix_W=fix_W, fix_T=fix_T, project_T_each_iter=project_T_each_iter,

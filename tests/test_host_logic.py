@@ -154,6 +154,42 @@ def test_stop_rules_and_init():
         initialize_nmf(planted_X(10, 8, 2, dtype=np.float64), 2, init='coherence_pmi')
 
 
+class _HostProducts(object):
+    """stands in for RRIEngine.X_times / Xt_times (the only two things randomized_svd_device asks of an engine)"""
+    def __init__(self, X):
+        self.X, (self.n, self.d) = X, X.shape
+        self.calls = 0
+
+    def X_times(self, B):
+        self.calls += 1
+        return self.X @ B
+
+    def Xt_times(self, Q):
+        self.calls += 1
+        return self.X.T @ Q
+
+
+@pytest.mark.parametrize('shape,k', [((300, 120), 5), ((90, 400), 6), ((200, 40), 10)])
+def test_device_randomized_svd_follows_sklearn(shape, k):
+    """same test matrix, same normaliser, same sign convention as sklearn.utils.extmath.randomized_svd (what the
+    reference's initialization.py:105 calls): tall, wide (transposed internally) and k >= 0.1 min(n, d) (4 power
+    iterations instead of 7) cases"""
+    from sklearn.utils.extmath import randomized_svd
+    from rri_nmf_amd.initialization import randomized_svd_device, initialize_nmf
+    X = planted_X(shape[0], shape[1], k, dtype=np.float64)
+    fake = _HostProducts(X)
+    U, S, V = randomized_svd_device(fake, k, random_state=4)
+    U0, S0, V0 = randomized_svd(X, k, random_state=4)
+    assert U.shape == U0.shape and V.shape == V0.shape
+    assert np.allclose(S, S0, rtol=1e-12, atol=0)
+    assert np.abs(U - U0).max() < 1e-9 and np.abs(V - V0).max() < 1e-9
+    assert fake.calls == 2 * (7 if k < 0.1 * min(shape) else 4) + 2
+    for init in ('nndsvd', 'nndsvda', 'nndsvdar'):
+        a = initialize_nmf(X, k, init=init, random_state=4, engine=fake)
+        b = initialize_nmf(X, k, init=init, random_state=4)
+        assert np.abs(a[0] - b[0]).max() < 1e-8 and np.abs(a[1] - b[1]).max() < 1e-8, init
+
+
 def test_initialize_and_validate_matches_oracle():
     from rri_nmf_amd.nmf import _initialize_and_validate
     X = planted_X(50, 40, 4, dtype=np.float64)

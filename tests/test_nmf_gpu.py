@@ -294,3 +294,45 @@ def test_sparse_inputs_are_ingested_as_csr():
         bad.indices[0] = 500
         with pytest.raises(ValueError, match='column index'):
             e.upload_X_csr(bad)
+
+
+@pytest.mark.parametrize('shape,store', [((700, 333), np.float64), ((257, 1030), np.float32)])
+def test_device_products_and_device_init(shape, store):
+    """rri_X_times / rri_Xt_times against numpy, and nmf(init='nndsvd') started from the device-assisted SVD
+    against the same call started from scikit-learn's (same algorithm: the two must agree to rounding)"""
+    from rri_nmf_amd.engine import RRIEngine
+    from rri_nmf_amd.initialization import randomized_svd_device
+    from sklearn.utils.extmath import randomized_svd
+    nmf_mod, _ = api()
+    n, d = shape
+    k = 6
+    X = planted_X(n, d, k, dtype=store)
+    X64 = X.astype(np.float64)
+    rs = np.random.RandomState(1)
+    B, Q = rs.randn(d, 9), rs.randn(n, 5)
+    eng = RRIEngine(n, d, k, dtype=store)
+    eng.upload_X(X)
+    assert relfro(eng.X_times(B), X64 @ B) < 1e-13
+    assert relfro(eng.Xt_times(Q), X64.T @ Q) < 1e-13
+    assert relfro(eng.X_times(B[:, :1]), X64 @ B[:, :1]) < 1e-13       # a single vector
+    U, S, V = randomized_svd_device(eng, k, random_state=3)
+    U0, S0, V0 = randomized_svd(X64, k, random_state=3)
+    assert np.allclose(S, S0, rtol=1e-10) and np.abs(U - U0).max() < 1e-8 and np.abs(V - V0).max() < 1e-8
+    # the products do not disturb a factorisation in progress
+    W0, T0 = scaled_init(X64, k, seed=2)
+    eng.set_W(W0), eng.set_T(T0)
+    eng.set_params()
+    eng.sweep(1)
+    eng.Xt_times(Q), eng.X_times(B)
+    eng.sweep(1)
+    Wa, Ta = eng.get_W(), eng.get_T()
+    eng.set_W(W0), eng.set_T(T0)
+    eng.sweep(2)
+    assert relfro(Wa, eng.get_W()) < 1e-13 and relfro(Ta, eng.get_T()) < 1e-13
+    del eng
+    kw = dict(max_iter=5, random_state=0, project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0, eps_stop=-1)
+    a = nmf_mod.nmf(X, k, device_init=True, **kw)
+    b = nmf_mod.nmf(X, k, device_init=False, **kw)
+    # scikit-learn factorises a float32 X in float32 arithmetic; the device products are float64 either way
+    tol = 1e-6 if store == np.float64 else 1e-3
+    assert relfro(a['W'], b['W']) < tol and relfro(a['T'], b['T']) < tol

@@ -161,12 +161,10 @@ def main():
     torch.cuda.synchronize()
 
     weighted = bool(cfg.get('weighted'))
-    if weighted and sharded:
-        raise SystemExit('the weighted workload is single-GPU')
     Mask = None
     if weighted:
         gm = torch.Generator(device=device)
-        gm.manual_seed(2)
+        gm.manual_seed(2 if world == 1 else 3000 + rank)
         Mask = (torch.rand(n_local, d, device=device, generator=gm) < 0.05).to(torch.float32)
         X.mul_(Mask)
         torch.cuda.synchronize()
@@ -235,7 +233,7 @@ def main():
                    'n_global': n_global, 'n_per_gpu': n_local, 'd': d, 'k': k,
                    'x_storage': 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
                    'parallelism': 'row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step'
-                                  % (world, d + 8 * (k + 2)) if world > 1 else 'single GPU'},
+                                  % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2))) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                      'kernel': ('k_wpass<float,...> passes B (read E, mask) and C (read E, mask; write E), averaged; mask '

@@ -158,7 +158,10 @@ rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 /* A topic step splits at the one cross-row reduction it needs.  rri_topic_reduce_local
  * leaves this rank's partial sums [w_t^T X (d) | w_t^T W (k) | ||w_t||^2 | sum W[:,t-1] | pad]
  * in the reduce buffer; the caller all-reduces (sum) that buffer over the ranks (RCCL over
- * xGMI via torch.distributed) and calls rri_topic_finish, which is rank-local. */
+ * xGMI via torch.distributed) and calls rri_topic_finish, which is rank-local.
+ * Weighted handles (WRRI, nmf.py:687-701): the buffer is [numerator w_t^T Rt (LD) | denominator
+ * (w_t^2)^T M (LD) | sum of W[:,t-1], its negative-denominator flag], LD = d rounded up to the
+ * 16-byte row stride; same protocol (one all-reduce of [numerator | denominator] per topic). */
 rri_status rri_reduce_buffer(rri_ctx* ctx, void** dev_ptr, int64_t* n_elems); /* dtype = handle's */
 rri_status rri_bind_reduce_buffer(rri_ctx* ctx, void* dev_ptr, int64_t n_elems);
 rri_status rri_topic_reduce_local(rri_ctx* ctx, int32_t t);

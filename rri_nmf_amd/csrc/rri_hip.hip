@@ -73,6 +73,8 @@ struct rri_ctx {
     int nsplit = 4;  // column slices of k_tgram
     bool own_red = false;
     i64 red_elems = 0;
+    bool resid_fresh = false;   // weighted: E was rebuilt and no half step has run since
+    bool dt_pending = false;    // weighted: dtv holds a T-row change that E does not contain yet
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
     double *dtmp = nullptr;  // small double scratch (device): [0] sum, ...
     i64* itmp = nullptr;     // small i64 scratch (device)
@@ -569,6 +571,8 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
 void w_refresh(rri_ctx* c) {
     DISPATCH(c, L::resid(c, true, true, nullptr, nullptr));   // E = M .* (X - W T)
     c->resid_valid = true;
+    c->resid_fresh = true;
+    c->dt_pending = false;     // the rebuilt E contains the current T
     c->carry_valid = false;
 }
 
@@ -580,13 +584,20 @@ void w_reduce(rri_ctx* c) {
                        (const double*)nullptr, 0, c->k, c->red + c->LD, (const DevState*)c->st);
 }
 
-void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
+// column sums (a, nw) of topic t over the current E into red[0 .. 2 LD)
+void enqueue_wT_sums(rri_ctx* c, int t) {
     const double* wt_t = c->W + (i64)t * c->ldw;
     if (!c->carry_valid || c->carry_topic != t)
         DISPATCH(c, (L::template wpass<false, true, false, false>(c, nullptr, wt_t, c->zeros, c->zeros, nullptr, nullptr)));
+    TimedScope ts(c, 2);
+    w_reduce(c);
+}
+
+// T row from red (local sums, or all-reduced ones on the row-sharded path)
+void enqueue_wT_solve(rri_ctx* c, int sweep, int t) {
+    const double* wt_t = c->W + (i64)t * c->ldw;
     {
         TimedScope ts(c, 2);
-        w_reduce(c);
         hipLaunchKernelGGL(k_wtrow, dim3(c->ntb), dim3(128), 0, c->stream, (const double*)c->T, c->LD, (int)c->d, t,
                            (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, kparams(c),
                            (const DevState*)c->st);
@@ -596,17 +607,28 @@ void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
                            kparams(c), c->st);
     }
     c->carry_valid = false;
+    c->resid_fresh = false;
+    c->dt_pending = true;
     if (c->prm.fix_W) {   // no W half follows: fold dt into E now, then rescale the kept column (nmf.py:450-452)
         DISPATCH(c, (L::template wpass<false, false, false, true>(c, nullptr, nullptr, wt_t, c->dtv, nullptr, nullptr)));
+        c->dt_pending = false;
         if (no_regs(c)) LK::scale_wcol(c, t);
     }
 }
 
-void enqueue_wW_half(rri_ctx* c, int sweep, int t) {
+void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
+    enqueue_wT_sums(c, t);
+    enqueue_wT_solve(c, sweep, t);
+}
+
+void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     const int k = c->k;
     const int tn = (t + 1) % k;
     const double* trow = c->T + (i64)t * c->LD;
-    const double* b1 = c->prm.fix_T ? c->zeros : c->dtv;   // pending T-row correction (none when T is fixed)
+    // pending T-row correction: none when T is fixed, or when E was rebuilt after the row changed (reset + resume)
+    const double* b1 = (c->prm.fix_T || !c->dt_pending) ? c->zeros : c->dtv;
+    c->dt_pending = false;
+    c->resid_fresh = false;
     DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->W + (i64)t * c->ldw, b1, nullptr, nullptr)));
     {
         TimedScope ts(c, 1);
@@ -620,8 +642,13 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t) {
     else DISPATCH(c, (L::template wpass<false, false, true, true>(c, nullptr, nullptr, c->wold, b1, c->dwv, trow)));
     int ns = sweep, np = t + 1;
     if (np == k) { np = 0; ns = sweep + 1; }
-    hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, k, t, ns, np,
-                       kparams(c), c->st);
+    if (defer_check) {   // row-sharded: the verdict needs the global column sum (rri_topic_reduce_local parks it)
+        c->pending_wcheck = true;
+        c->pending_wcheck_topic = t;
+    } else {
+        hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, k, t, ns,
+                           np, kparams(c), c->st, (double*)nullptr);
+    }
     c->carry_valid = carry_next;
     c->carry_topic = tn;
 }
@@ -769,7 +796,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->ntb = (int)((d + 127) / 128);
     c->ldw = n;
     c->nsplit = (int)std::max<i64>(1, std::min<i64>(8, d / 2048));
-    c->red_elems = round_up(std::max<i64>(c->LD + (i64)GRAM_SLICES * (k + 2), weighted ? 2 * c->LD : 0), 4);
+    c->red_elems = round_up(std::max<i64>(c->LD + (i64)GRAM_SLICES * (k + 2), weighted ? 2 * c->LD + 2 : 0), 4);
 
     const size_t f8 = sizeof(double);
     const size_t es_x = c->es;
@@ -1364,10 +1391,21 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
     CHECK_CTX(c);
     rri_status r = ready(c);
     if (r != RRI_OK) return r;
-    if (c->weighted || c->prm.fix_W || c->prm.fix_T || c->k < 2)
-        return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping covers the unweighted flavour with k >= 2 and both halves free");
+    if (c->prm.fix_W || c->prm.fix_T || c->k < 2)
+        return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping needs k >= 2 and both halves free");
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->weighted) {
+        // red = [a (LD) | nw (LD) | sum and negative-denominator flag of the last updated column]
+        if (!c->resid_valid || (t == 0 && !c->resid_fresh)) w_refresh(c);     // once per sweep, as rri_sweep
+        enqueue_wT_sums(c, t);
+        if (c->pending_wcheck)
+            hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, c->k,
+                               c->pending_wcheck_topic, 0, t, kparams(c), c->st, c->red + 2 * c->LD);
+        else
+            HIPCHK(c, hipMemsetAsync(c->red + 2 * c->LD, 0, 2 * sizeof(double), c->stream));
+        return RRI_OK;
+    }
     if (!c->carry_valid || c->carry_topic != t) {
         // a local column check would see only this rank's rows: keep it pending for the reduced buffer
         const bool pend = c->pending_wcheck;
@@ -1385,6 +1423,17 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
 rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->weighted) {
+        if (t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
+        if (c->pending_wcheck)
+            hipLaunchKernelGGL(k_wcheck_tail, dim3(1), dim3(64), 0, c->stream, (const double*)(c->red + 2 * c->LD),
+                               c->pending_wcheck_topic, 0, t < 0 ? 0 : t, kparams(c), c->st);
+        c->pending_wcheck = false;
+        if (t < 0) return RRI_OK;
+        enqueue_wT_solve(c, 0, t);
+        enqueue_wW_half(c, 0, t, true);
+        return RRI_OK;
+    }
     if (t < 0) {  // only the pending column check, against the (all-reduced) buffer
         if (c->pending_wcheck) {
             LK::check_prev_only(c, c->pending_wcheck_topic, 0, 0);
@@ -1405,6 +1454,11 @@ rri_status rri_topic_finish_w(rri_ctx* c, int32_t t) {
     CHECK_CTX(c);
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->weighted) {           // after a T-row reset: E is rebuilt from the new row and column
+        if (!c->resid_valid) w_refresh(c);
+        enqueue_wW_half(c, 0, t, true);
+        return RRI_OK;
+    }
     c->skip_row_finish = true;   // the T-row sums of this topic predate the reset
     enqueue_W_half(c, 0, t);
     return RRI_OK;

@@ -352,9 +352,26 @@ __global__ __launch_bounds__(256) void k_wwcol(double* __restrict__ Wt, i64 ldw,
 }
 
 // column check for the weighted flavour: unbounded (negative denominator without ub) first, then the
-// reset / assert logic of k_check_wcol
+// reset / assert logic of k_check_wcol.  (a, f) = (sum of the new column, 1 when a negative denominator was seen).
+__device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int sweep, int pos, const KParams& p,
+                                             DevState* st) {
+    if (f > 0.0 && !p.has_wrs) {
+        st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+        return;
+    }
+    const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+    const bool err = !ev && !(a > 0.0);
+    if (ev || err) {
+        st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+        st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+    }
+}
+
+// tail == NULL: decide from this handle's rows.  tail != NULL (row-sharded): only park the local (a, f) in
+// tail[0..1]; the verdict is k_wcheck_tail's, on the all-reduced pair.
 __global__ __launch_bounds__(256) void k_wcheck_wcol(const double* __restrict__ Gpart, int nwb, int k, int tprev,
-                                                     int sweep, int pos, KParams p, DevState* st) {
+                                                     int sweep, int pos, KParams p, DevState* st,
+                                                     double* __restrict__ tail) {
     if (st->halt) return;
     __shared__ double scratch[40];
     double a = 0.0, f = 0.0;
@@ -365,17 +382,15 @@ __global__ __launch_bounds__(256) void k_wcheck_wcol(const double* __restrict__ 
     a = block_sum(a, scratch);
     f = block_sum(f, scratch);
     if (threadIdx.x == 0) {
-        if (f > 0.0 && !p.has_wrs) {
-            st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
-            return;
-        }
-        const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
-        const bool err = !ev && !(a > 0.0);
-        if (ev || err) {
-            st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
-        }
+        if (tail) { tail[0] = a; tail[1] = f; }
+        else wcol_verdict(a, f, tprev, sweep, pos, p, st);
     }
+}
+
+__global__ __launch_bounds__(64) void k_wcheck_tail(const double* __restrict__ tail, int tprev, int sweep, int pos,
+                                                    KParams p, DevState* st) {
+    if (st->halt) return;
+    if (threadIdx.x == 0) wcol_verdict(tail[0], tail[1], tprev, sweep, pos, p, st);
 }
 
 }  // namespace rri

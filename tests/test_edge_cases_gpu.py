@@ -66,6 +66,12 @@ CASES = {
     'weighted_unbounded': lambda: (rnd(0, 30, 20), 3, rnd(1, 30, 3), rnd(2, 3, 20),
                                    dict(max_iter=2, W_mat=(rnd(5, 30, 20) < 0.5).astype(float), reg_t_l2=-5.0,
                                         t_row_sum=None, project_T_each_iter=True)),
+    'weighted_T_row_resets': lambda: (rnd(0, 60, 40) * (rnd(5, 60, 40) < 0.5), 3, rnd(1, 60, 3), rnd(2, 3, 40),
+                                      dict(max_iter=2, W_mat=(rnd(5, 60, 40) < 0.5).astype(float), t_row_sum=1.0,
+                                           reg_t_l1=1e6, reset_topic_method='max_resid_document')),
+    'weighted_W_col_resets': lambda: (rnd(0, 60, 40) * (rnd(5, 60, 40) < 0.5), 3, rnd(1, 60, 3), rnd(2, 3, 40),
+                                      dict(max_iter=2, W_mat=(rnd(5, 60, 40) < 0.5).astype(float), t_row_sum=1.0,
+                                           reg_w_l1=1e6, reset_topic_method='max_resid_document')),
     'fp32_input_ragged_d': lambda: (rnd(0, 130, 1027).astype(np.float32), 5, rnd(1, 130, 5), rnd(2, 5, 1027),
                                     dict(max_iter=3)),
 }

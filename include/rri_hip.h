@@ -52,6 +52,7 @@ enum {
 };
 
 enum { RRI_F32 = 0, RRI_F64 = 1 };   /* storage type of X, mask, residual in HBM (arithmetic is float64) */
+enum { RRI_UNWEIGHTED = 0, RRI_WEIGHTED_DENSE = 1, RRI_WEIGHTED_SPARSE = 2 };   /* rri_create's `weighted` */
 enum { RRI_RESET_NONE = 0, RRI_RESET_MAX_RESID_DOCUMENT = 1, RRI_RESET_RANDOM = 2 };
 enum { RRI_EVENT_NONE = 0, RRI_EVENT_RESET_T = 1, RRI_EVENT_RESET_W = 2 };
 
@@ -82,8 +83,9 @@ typedef struct rri_event {
 
 /* ---- lifetime ------------------------------------------------------------------ */
 uint32_t   rri_abi_version(void);
-/* dtype: RRI_F32 / RRI_F64.  weighted != 0 reserves the mask and masked-residual
- * buffers of the elementwise-weighted flavour (WRRI, nmf.py:687-701,735-746).
+/* dtype: RRI_F32 / RRI_F64.  weighted: RRI_UNWEIGHTED; RRI_WEIGHTED_DENSE reserves the mask and masked-residual
+ * buffers of the elementwise-weighted flavour (WRRI, nmf.py:687-701,735-746) as dense n x d arrays;
+ * RRI_WEIGHTED_SPARSE keeps that flavour on a 0/1 observation pattern only (rri_upload_observed_csr).
  * device: HIP device ordinal.  stream: hipStream_t to run on, or NULL for an own stream. */
 rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dtype,
                       int32_t weighted, int32_t device, void* stream);
@@ -105,6 +107,13 @@ rri_status rri_upload_X_csr(rri_ctx* ctx, const int64_t* indptr, const int32_t* 
                             int64_t nnz, int32_t data_dtype);
 rri_status rri_upload_mask_csr_pattern(rri_ctx* ctx, const int64_t* indptr, const int32_t* indices,
                                        const void* data, int64_t nnz, int32_t data_dtype);
+/* RRI_WEIGHTED_SPARSE handles: W_mat is the 0/1 pattern of a CSR matrix and X is given on that pattern only
+ * (values[p] = X[r, indices[p]], explicit zeros allowed; X is taken as 0 elsewhere, where W_mat = 0 hides it from
+ * every sum of nmf.py:687-746 and the reset search of nmf.py:770-773 sees max(0 - WT, 0) = 0).  The recommender
+ * case of sklearn_interface.py:78-102 without any dense n x d array: the residual is kept on the pattern, as a
+ * CSR and a CSC copy.  Replaces rri_upload_X + rri_upload_mask for such a handle. */
+rri_status rri_upload_observed_csr(rri_ctx* ctx, const int64_t* indptr, const int32_t* indices,
+                                   const void* values, int64_t nnz, int32_t data_dtype);
 rri_status rri_set_W(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);  /* n*k */
 rri_status rri_set_T(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);  /* k*d */
 rri_status rri_get_W(rri_ctx* ctx, void* host, int64_t ld, int32_t host_dtype);

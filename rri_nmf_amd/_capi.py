@@ -48,6 +48,7 @@ PROTOTYPES = {
     'rri_bind_mask_device': (_I32, [_P, _P, _I64]),
     'rri_upload_X_csr': (_I32, [_P, C.POINTER(_I64), C.POINTER(_I32), _P, _I64, _I32]),
     'rri_upload_mask_csr_pattern': (_I32, [_P, C.POINTER(_I64), C.POINTER(_I32), _P, _I64, _I32]),
+    'rri_upload_observed_csr': (_I32, [_P, C.POINTER(_I64), C.POINTER(_I32), _P, _I64, _I32]),
     'rri_set_W': (_I32, [_P, _P, _I64, _I32]),
     'rri_set_T': (_I32, [_P, _P, _I64, _I32]),
     'rri_get_W': (_I32, [_P, _P, _I64, _I32]),

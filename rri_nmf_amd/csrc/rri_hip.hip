@@ -27,6 +27,7 @@
 #include "rri_hip.h"
 #include "rri_kernels.hpp"
 #include "rri_wrri_kernels.hpp"
+#include "rri_sparse_kernels.hpp"
 
 using namespace rri;
 
@@ -73,6 +74,15 @@ struct rri_ctx {
     int nsplit = 4;  // column slices of k_tgram
     bool own_red = false;
     i64 red_elems = 0;
+    // weighted flavour on a CSR observation pattern (rri_upload_observed_csr): no dense n x d array at all
+    bool sparse = false;
+    i64 nnz = 0;
+    int sp_max_row = 0, sp_lps_row = 64, sp_lps_col = 64, kp = 8;
+    i64 *sp_rowptr = nullptr, *sp_colptr = nullptr;
+    int *sp_col = nullptr, *sp_row = nullptr, *sp_perm = nullptr;
+    void *sp_x = nullptr, *sp_e = nullptr, *sp_ec = nullptr;   // values on the pattern: X, residual (CSR), residual (CSC)
+    SpGather *sp_gd = nullptr, *sp_gn = nullptr;               // packed gather tables over the columns / the rows
+    double* sp_Tt = nullptr;                                   // T transposed, d x kp
     bool resid_fresh = false;   // weighted: E was rebuilt and no half step has run since
     bool dt_pending = false;    // weighted: dtv holds a T-row change that E does not contain yet
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
@@ -248,6 +258,7 @@ struct LaunchX {
     static void wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                       const double* a2, const double* b2) {
         TimedScope ts(c, 3);
+        if (c->sparse) { sp_wpass<DO_Y, DO_Z, UPD2, WRITE>(c, trow, wc, a1, b1, a2, b2); return; }
         // rows in flight: 8 for the passes that take row products (they use the LDS row sums), 4 for the
         // writing pass (two rank-one corrections and two sets of accumulators: 4 rows keep it at 4 waves/SIMD)
         constexpr int U = DO_Y ? 8 : 4;
@@ -259,6 +270,57 @@ struct LaunchX {
             if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
             else wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, U, false>(c, trow, wc, a1, b1, a2, b2);
         }
+    }
+    // ---- sparse pattern (rri_sparse_kernels.hpp) ----------------------------------------------------
+    static void sp_pack(rri_ctx* c, const double* B1, const double* B2, const double* V, i64 m, SpGather* G) {
+        hipLaunchKernelGGL(k_sp_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, B1, B2, V, m, G,
+                           (const DevState*)c->st);
+    }
+    template <bool DO_S, bool UPD2, bool WRITE>
+    static void sp_seg(rri_ctx* c, bool csc, const double* A1, const double* A2, double* S1, double* S2) {
+        const i64 nseg = csc ? c->d : c->n;
+        const int lps = csc ? c->sp_lps_col : c->sp_lps_row;
+        const i64* ptr = csc ? c->sp_colptr : c->sp_rowptr;
+        const int* idx = csc ? c->sp_row : c->sp_col;
+        SX* val = (SX*)(csc ? c->sp_ec : c->sp_e);
+        const SpGather* G = csc ? c->sp_gn : c->sp_gd;
+        const unsigned nb = (unsigned)((nseg * lps + 255) / 256);
+#define RRI_SEG(LPS_)                                                                                              \
+    hipLaunchKernelGGL((k_sp_seg<SX, DO_S, UPD2, WRITE, LPS_>), dim3(nb), dim3(256), 0, c->stream, ptr, idx, val, nseg, \
+                       A1, A2, G, S1, S2, (const DevState*)c->st)
+        switch (lps) {
+            case 8: RRI_SEG(8); break;
+            case 16: RRI_SEG(16); break;
+            case 32: RRI_SEG(32); break;
+            default: RRI_SEG(64); break;
+        }
+#undef RRI_SEG
+    }
+    // the same operation as wpass on the two copies of the pattern residual: row products from the CSR copy
+    // (into Ypart / Y2part, one "panel"), column sums from the CSC copy (straight into red = [a | nw])
+    template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
+    static void sp_wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
+                         const double* a2, const double* b2) {
+        if (DO_Y || WRITE) {
+            sp_pack(c, b1, UPD2 ? b2 : nullptr, DO_Y ? trow : nullptr, c->d, c->sp_gd);
+            sp_seg<DO_Y, UPD2, WRITE>(c, false, a1, a2, c->Ypart, c->Y2part);
+        }
+        if (DO_Z || WRITE) {
+            sp_pack(c, a1, UPD2 ? a2 : nullptr, DO_Z ? wc : nullptr, c->n, c->sp_gn);
+            sp_seg<DO_Z, UPD2, WRITE>(c, true, b1, b2, c->red, c->red + c->LD);
+        }
+    }
+    static void sp_resid(rri_ctx* c, bool write_e, double* rowobj, double* rowpos) {
+        const i64 total = (i64)c->k * c->d;
+        hipLaunchKernelGGL((k_convert2d<double, double, true>), dim3((unsigned)std::min<i64>(4096, (total + 255) / 256)),
+                           dim3(256), 0, c->stream, (const double*)c->T, c->LD, c->sp_Tt, (i64)c->kp, (i64)c->k, c->d);
+        hipLaunchKernelGGL((k_sp_resid<SX>), dim3((unsigned)((c->n + 3) / 4)), dim3(256), 4 * (size_t)c->kp * sizeof(double),
+                           c->stream, (const i64*)c->sp_rowptr, (const int*)c->sp_col, (const SX*)c->sp_x, c->n,
+                           (const double*)c->W, c->ldw, (const double*)c->sp_Tt, c->k, c->kp,
+                           write_e ? (SX*)c->sp_e : (SX*)nullptr, rowobj, rowpos);
+        if (write_e && c->nnz > 0)
+            hipLaunchKernelGGL((k_sp_permute<SX>), dim3(2048), dim3(256), 0, c->stream, (const SX*)c->sp_e,
+                               (const int*)c->sp_perm, c->nnz, (SX*)c->sp_ec);
     }
     // 0/1 masks are bit-packed (32 columns per word): the mask then costs 1/32 of its fp32 bytes per pass
     static rri_status pack_mask_if_binary(rri_ctx* c) {
@@ -297,6 +359,7 @@ struct LaunchX {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
     }
     static void resid(rri_ctx* c, bool masked, bool write_e, double* rowobj, double* rowpos) {
+        if (c->sparse) { sp_resid(c, write_e, rowobj, rowpos); return; }   // outside the pattern nothing contributes
         const unsigned nb = (unsigned)((c->n + 63) / 64);
         const size_t sh = resid_shmem(c);
 #define RRI_RESID(MK, WE)                                                                                       \
@@ -310,6 +373,14 @@ struct LaunchX {
 #undef RRI_RESID
     }
     static void reset_row(rri_ctx* c) {
+        if (c->sparse) {
+            (void)hipMemsetAsync(c->xraw, 0, (size_t)c->LD * sizeof(double), c->stream);
+            hipLaunchKernelGGL((k_sp_reset_row<SX>), dim3((unsigned)std::max(1, (c->sp_max_row + 255) / 256)), dim3(256), 0,
+                               c->stream, (const i64*)c->sp_rowptr, (const int*)c->sp_col, (const SX*)c->sp_x,
+                               (const double*)c->W, c->ldw, (const double*)c->T, c->LD, c->k, (const i64*)c->itmp,
+                               c->xraw);
+            return;
+        }
         hipLaunchKernelGGL((k_reset_row<SX>), dim3((unsigned)((c->d + 255) / 256)), dim3(256), 0, c->stream,
                            (const SX*)c->X, c->ldx, (const double*)c->W, c->ldw, (const double*)c->T, c->LD,
                            (int)c->d, c->k, (const i64*)c->itmp, c->xraw);
@@ -577,6 +648,7 @@ void w_refresh(rri_ctx* c) {
 }
 
 void w_reduce(rri_ctx* c) {
+    if (c->sparse) return;   // the CSC pass leaves the column sums in red itself
     const int nb = (int)((c->LD + 31) / 32);
     hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
                        (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
@@ -753,8 +825,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, RRI_ERR_HIP, "no HIP device available (librri_hip needs an MI355X)");
     if (device < 0 || device >= ndev) return fail(nullptr, RRI_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    if (weighted < 0 || weighted > 2) return fail(nullptr, RRI_ERR_INVALID, "weighted must be 0, 1 or 2 (sparse pattern)");
     rri_ctx* c = new rri_ctx();
     c->n = n; c->d = d; c->k = k; c->dtype = dtype; c->weighted = weighted; c->device = device;
+    c->sparse = weighted == RRI_WEIGHTED_SPARSE;
+    c->kp = (int)round_up(k, 8);
     c->es = dtype == RRI_F32 ? 4 : 8;
     c->VN = (int)(16 / c->es);
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) g_pass_unroll = v; }
@@ -791,6 +866,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     rpb = std::min<i64>(round_up(rpb, 16), rpb_cap);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
+    if (c->sparse) { c->npanels = 1; c->nrb = 1; }   // no dense pass: row products / column sums arrive complete
     c->nwb = (int)((n + 64 * WCOL_TILES - 1) / (64 * WCOL_TILES));   // k_wcol blocks = rows of Gpart
     c->nwb256 = (int)((n + 255) / 256);
     c->ntb = (int)((d + 127) / 128);
@@ -825,7 +901,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->itmp, 16 * sizeof(i64)));
     if (weighted) {
         const i64 zn = std::max<i64>(c->LD, n);
-        CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+        if (!c->sparse) CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
         CR(hipMalloc((void**)&c->Y2part, (size_t)c->npanels * n * f8));
         CR(hipMalloc((void**)&c->Z2part, (size_t)c->nrb * c->LD * f8));
         CR(hipMalloc((void**)&c->dtv, (size_t)c->LD * f8));
@@ -834,6 +910,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         CR(hipMalloc((void**)&c->zeros, (size_t)zn * f8));
         CR(hipMemsetAsync(c->zeros, 0, (size_t)zn * f8, c->stream));
         CR(hipMemsetAsync(c->dtv, 0, (size_t)c->LD * f8, c->stream));
+        if (c->sparse) {
+            CR(hipMalloc((void**)&c->sp_gd, (size_t)d * sizeof(SpGather)));
+            CR(hipMalloc((void**)&c->sp_gn, (size_t)n * sizeof(SpGather)));
+            CR(hipMalloc((void**)&c->sp_Tt, (size_t)d * c->kp * f8));
+            CR(hipMemsetAsync(c->sp_Tt, 0, (size_t)d * c->kp * f8, c->stream));
+        }
     }
     CR(hipMalloc((void**)&c->st, sizeof(DevState)));
     CR(hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream));
@@ -855,7 +937,9 @@ rri_status rri_destroy(rri_ctx* c) {
     void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
-                    (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros};
+                    (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
+                    (void*)c->sp_rowptr, (void*)c->sp_colptr, (void*)c->sp_col, (void*)c->sp_row, (void*)c->sp_perm, c->sp_x,
+                    c->sp_e, c->sp_ec, (void*)c->sp_gd, (void*)c->sp_gn, (void*)c->sp_Tt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -870,6 +954,7 @@ rri_status rri_destroy(rri_ctx* c) {
 // ---- data ------------------------------------------------------------------------------------------
 rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->X && !c->own_X) c->X = nullptr;
     if (!c->X) {
@@ -885,6 +970,7 @@ rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_d
 
 rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->M && !c->own_M) c->M = nullptr;
@@ -937,6 +1023,7 @@ rri_status csr_to_device(rri_ctx* c, const int64_t* indptr, const int32_t* indic
 rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
                             int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     HIPCHK(c, hipSetDevice(c->device));
     CsrDev dv;
     rri_status s = csr_to_device(c, indptr, indices, data, nnz, data_dtype, dv);
@@ -966,6 +1053,7 @@ rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* in
 rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
                                        int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     HIPCHK(c, hipSetDevice(c->device));
     CsrDev dv;
@@ -989,8 +1077,80 @@ rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const 
     return RRI_OK;
 }
 
+rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* values,
+                                   int64_t nnz, int32_t data_dtype) {
+    CHECK_CTX(c);
+    if (!c->sparse) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=RRI_WEIGHTED_SPARSE");
+    if (nnz >= 2147483647LL) return fail(c, RRI_ERR_UNSUPPORTED, "more than 2^31-1 observed entries");
+    HIPCHK(c, hipSetDevice(c->device));
+    CsrDev dv;   // validates the arrays; its device copies of indptr / indices become the CSR copy
+    rri_status s = csr_to_device(c, indptr, indices, values, nnz, data_dtype, dv);
+    if (s != RRI_OK) return s;
+    // column-major copy of the pattern: counting sort on the host (stable: rows ascend inside a column)
+    std::vector<i64> colptr((size_t)c->d + 1, 0);
+    for (i64 p = 0; p < nnz; ++p) colptr[(size_t)indices[p] + 1] += 1;
+    i64 longest_col = 0;
+    for (i64 j = 0; j < c->d; ++j) {
+        longest_col = std::max(longest_col, colptr[(size_t)j + 1]);
+        colptr[(size_t)j + 1] += colptr[(size_t)j];
+    }
+    std::vector<int> rowidx((size_t)std::max<i64>(nnz, 1)), perm((size_t)std::max<i64>(nnz, 1));
+    {
+        std::vector<i64> fill(colptr.begin(), colptr.end() - 1);
+        for (i64 r = 0; r < c->n; ++r)
+            for (i64 p = indptr[r]; p < indptr[r + 1]; ++p) {
+                const i64 q = fill[(size_t)indices[p]]++;
+                rowidx[(size_t)q] = (int)r;
+                perm[(size_t)q] = (int)p;
+            }
+    }
+    i64 longest_row = 0;
+    for (i64 r = 0; r < c->n; ++r) longest_row = std::max<i64>(longest_row, (i64)(indptr[r + 1] - indptr[r]));
+    void* old[] = {(void*)c->sp_rowptr, (void*)c->sp_colptr, (void*)c->sp_col, (void*)c->sp_row, (void*)c->sp_perm,
+                   c->sp_x, c->sp_e, c->sp_ec};
+    for (void* b : old)
+        if (b) (void)hipFree(b);
+    c->sp_rowptr = dv.indptr; dv.indptr = nullptr;
+    c->sp_col = dv.indices; dv.indices = nullptr;
+    c->sp_colptr = nullptr; c->sp_row = nullptr; c->sp_perm = nullptr; c->sp_x = nullptr; c->sp_e = nullptr; c->sp_ec = nullptr;
+    const size_t cnt = (size_t)std::max<i64>(nnz, 1);
+    HIPCHK(c, hipMalloc((void**)&c->sp_colptr, (size_t)(c->d + 1) * sizeof(i64)));
+    HIPCHK(c, hipMalloc((void**)&c->sp_row, cnt * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->sp_perm, cnt * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->sp_x, cnt * c->es));
+    HIPCHK(c, hipMalloc(&c->sp_e, cnt * c->es));
+    HIPCHK(c, hipMalloc(&c->sp_ec, cnt * c->es));
+    HIPCHK(c, hipMemcpyAsync(c->sp_colptr, colptr.data(), (size_t)(c->d + 1) * sizeof(i64), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sp_row, rowidx.data(), cnt * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sp_perm, perm.data(), cnt * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) {   // values -> storage type (dv.data holds them in the caller's type)
+        const bool hf = data_dtype == RRI_F32, df = c->dtype == RRI_F32;
+        if (hf && df) launch_convert<float, float, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
+        else if (hf) launch_convert<float, double, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
+        else if (df) launch_convert<double, float, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
+        else launch_convert<double, double, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nnz = nnz;
+    c->sp_max_row = (int)longest_row;
+    auto lanes_for = [](i64 entries, i64 segments) {
+        const i64 avg = segments > 0 ? entries / segments : 0;
+        return avg >= 128 ? 64 : avg >= 64 ? 32 : avg >= 32 ? 16 : 8;
+    };
+    c->sp_lps_row = lanes_for(nnz, c->n);
+    c->sp_lps_col = lanes_for(nnz, c->d);
+    if (const char* e = getenv("RRI_SP_LANES_ROW")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) c->sp_lps_row = v; }
+    if (const char* e = getenv("RRI_SP_LANES_COL")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) c->sp_lps_col = v; }
+    (void)longest_col;
+    c->have_X = true;
+    c->have_M = true;
+    invalidate(c);
+    return RRI_OK;
+}
+
 rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
         return fail(c, RRI_ERR_INVALID, "device X must be 16-byte aligned with a 16-byte-multiple row stride >= d");
     if (c->d % c->VN) return fail(c, RRI_ERR_INVALID, "binding device X needs d %% %d == 0 (no pad columns)", c->VN);
@@ -1006,6 +1166,7 @@ rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
 
 rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
         return fail(c, RRI_ERR_INVALID, "device mask must be 16-byte aligned with a 16-byte-multiple row stride >= d");
@@ -1329,6 +1490,7 @@ rri_status rri_rollback(rri_ctx* c) {
 // ---- products with X for the initialisation -------------------------------------------------------------------
 rri_status rri_X_times(rri_ctx* c, const double* B, int32_t m, double* out) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
     if (!B || !out || m < 1) return fail(c, RRI_ERR_INVALID, "bad operand");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1345,6 +1507,7 @@ rri_status rri_X_times(rri_ctx* c, const double* B, int32_t m, double* out) {
 
 rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
     CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
     if (!Q || !out || m < 1) return fail(c, RRI_ERR_INVALID, "bad operand");
     HIPCHK(c, hipSetDevice(c->device));

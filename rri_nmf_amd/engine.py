@@ -34,6 +34,8 @@ class RRIEngine(object):
         self.dtype = np.dtype(dtype)
         if self.dtype not in _NP2RRI:
             raise ValueError('dtype must be float32 or float64')
+        # weighted: False | True (dense W_mat) | 'sparse' (0/1 W_mat given as a CSR pattern, upload_observed_csr)
+        self.sparse = weighted == 'sparse'
         self.weighted = bool(weighted)
         self._h = C.c_void_p()
         self.n_resets_used = 0
@@ -41,7 +43,7 @@ class RRIEngine(object):
         self.fix_reset_seed = False
         self._reset_method = None
         st = self._lib.rri_create(C.byref(self._h), self.n, self.d, self.k, _NP2RRI[self.dtype],
-                                  int(self.weighted), int(device), C.c_void_p(stream or 0))
+                                  2 if self.sparse else int(self.weighted), int(device), C.c_void_p(stream or 0))
         if st != _capi.RRI_OK:
             msg = self._lib.rri_last_error(None)
             self._h = C.c_void_p()
@@ -104,7 +106,13 @@ class RRIEngine(object):
         A = sp.csr_matrix(A)
         if A.shape != (self.n, self.d):
             raise ValueError('sparse matrix has wrong dimensions')
-        A.sum_duplicates()
+        if not A.has_canonical_format:      # never reorder the caller's arrays in place
+            A = A.copy()
+            A.sum_duplicates()
+        return self._csr_args_raw(A)
+
+    @staticmethod
+    def _csr_args_raw(A):
         data = A.data if A.data.dtype in _NP2RRI else A.data.astype(np.float64)
         indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(A.indices, dtype=np.int32)
@@ -122,6 +130,19 @@ class RRIEngine(object):
         """W_mat = [A != 0] of a scipy sparse matrix, bit-packed on the device"""
         keep, args = self._csr_args(A)
         self._check(self._lib.rri_upload_mask_csr_pattern(self._h, *args))
+
+    def upload_observed_csr(self, A):
+        """sparse-pattern handles: the stored entries of the scipy sparse matrix A are the observed ones
+        (W_mat = 1 there, explicit zeros included), A's values are X on them"""
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        if A.shape != (self.n, self.d):
+            raise ValueError('sparse matrix has wrong dimensions')
+        if not A.has_canonical_format:      # never reorder the caller's arrays in place
+            A = A.copy()
+            A.sum_duplicates()
+        keep, args = self._csr_args_raw(A)
+        self._check(self._lib.rri_upload_observed_csr(self._h, *args))
 
     def bind_X_device(self, ptr, ld):
         self._check(self._lib.rri_bind_X_device(self._h, C.c_void_p(ptr), int(ld)))

@@ -1,0 +1,104 @@
+"""The weighted flavour on a sparse observation pattern (RRI_WEIGHTED_SPARSE handles: residual kept on the pattern
+as a CSR and a CSC copy) against the dense weighted engine and the oracle, on the same inputs."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden, relfro
+from rri_nmf_amd.synthetic import planted_X, scaled_init
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, d, k, frac, seed=0, store=np.float64, empty=False):
+    rs = np.random.RandomState(seed + 10)
+    M = (rs.rand(n, d) < frac).astype(np.float64)
+    if empty:                      # rows / columns without any observation
+        M[3:7, :] = 0
+        M[:, 5:9] = 0
+    X = planted_X(n, d, k, seed=seed, dtype=np.float64) * M
+    X[M > 0] += 0.05               # observed entries are non-zero here; explicit zeros are covered separately
+    W0, T0 = scaled_init(X, k, seed=seed + 1)
+    return X.astype(store), M.astype(store), W0, T0
+
+
+def _run(X, M, W0, T0, k, sweeps, sparse, store, flags):
+    from rri_nmf_amd.engine import RRIEngine
+    n, d = X.shape
+    with RRIEngine(n, d, k, dtype=store, weighted='sparse' if sparse else True) as e:
+        if sparse:
+            A = sp.csr_matrix(M)                 # pattern
+            A.data = np.asarray(X[M > 0], dtype=store)     # row-major order = CSR order
+            e.upload_observed_csr(A)
+        else:
+            e.upload_X(X)
+            e.upload_mask(M)
+        e.set_W(W0), e.set_T(T0)
+        e.set_params(**flags)
+        e.sweep(sweeps)
+        return e.get_W(), e.get_T(), e.objective(), e.n_resets_used
+
+
+FLAGS = {
+    'rs_fit': dict(t_row_sum=1.0, reset_topic_method=None),
+    'rs_fit_regs': dict(t_row_sum=1.0, reset_topic_method=None, reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.1, reg_t_l2=0.05),
+    'projected': dict(t_row_sum=1.0, project_T_each_iter=True, w_row_sum=2.0, reset_topic_method=None),
+    'fix_T': dict(t_row_sum=1.0, fix_T=True, reset_topic_method='random'),
+    'fix_W': dict(t_row_sum=1.0, fix_W=True, reset_topic_method=None),
+    'resets_T': dict(t_row_sum=1.0, reg_t_l1=1e6),
+    'resets_W': dict(t_row_sum=1.0, reg_w_l1=1e6),
+}
+
+
+@pytest.mark.parametrize('name', sorted(FLAGS))
+@pytest.mark.parametrize('store', [np.float64, np.float32])
+def test_sparse_pattern_matches_dense_weighted_engine(name, store):
+    n, d, k = 413, 187, 5
+    X, M, W0, T0 = _problem(n, d, k, 0.2, store=store, empty=True)
+    flags = FLAGS[name]
+    Wd, Td, od, nd = _run(X, M, W0, T0, k, 3, False, store, flags)
+    Ws, Ts, os_, ns = _run(X, M, W0, T0, k, 3, True, store, flags)
+    tol = 1e-10 if store == np.float64 else 2e-5    # fp32: the two schedules round the stored residual differently
+    assert ns == nd
+    assert relfro(Ws, Wd) < tol and relfro(Ts, Td) < tol, (relfro(Ws, Wd), relfro(Ts, Td))
+    assert abs(os_ - od) <= max(tol, 1e-10) * abs(od)
+
+
+@pytest.mark.parametrize('frac,n,d', [(0.02, 900, 300), (0.6, 120, 90), (0.08, 64, 2100)])
+def test_sparse_pattern_matches_oracle(frac, n, d):
+    """short and long segments (8 ... 64 lanes per row / column), against the numpy restatement of nmf.py:687-746"""
+    from oracle import rri_oracle as orc
+    k = 4
+    X, M, W0, T0 = _problem(n, d, k, frac, seed=3)
+    kw = dict(t_row_sum=1.0, reset_topic_method=None)
+    Ws, Ts, _, _ = _run(X, M, W0, T0, k, 4, True, np.float64, kw)
+    ref = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), W_mat=M, max_iter=4, eps_stop=-1, **kw)
+    assert relfro(Ws, ref['W']) < 2e-9 and relfro(Ts, ref['T']) < 2e-9, (relfro(Ws, ref['W']), relfro(Ts, ref['T']))
+
+
+def test_explicit_zero_ratings_and_empty_pattern():
+    from rri_nmf_amd.engine import RRIEngine
+    from oracle import rri_oracle as orc
+    n, d, k = 60, 40, 3
+    X, M, W0, T0 = _problem(n, d, k, 0.3, seed=5)
+    obs = np.argwhere(M > 0)
+    for i, j in obs[::7]:
+        X[i, j] = 0.0                                   # observed, and the observed value is 0
+    A = sp.csr_matrix((X[M > 0], (obs[:, 0], obs[:, 1])), shape=(n, d))     # keeps the explicit zeros
+    assert A.nnz == int(M.sum())
+    kw = dict(t_row_sum=1.0, reset_topic_method=None)
+    with RRIEngine(n, d, k, dtype=np.float64, weighted='sparse') as e:
+        e.upload_observed_csr(A)
+        e.set_W(W0), e.set_T(T0)
+        e.set_params(**kw)
+        e.sweep(3)
+        Ws, Ts = e.get_W(), e.get_T()
+    ref = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), W_mat=M, max_iter=3, eps_stop=-1, **kw)
+    assert relfro(Ws, ref['W']) < 2e-9 and relfro(Ts, ref['T']) < 2e-9
+    # nothing observed at all: every column dies -> the reference's assertion (nmf.py:476)
+    with RRIEngine(n, d, k, dtype=np.float64, weighted='sparse') as e:
+        e.upload_observed_csr(sp.csr_matrix((n, d)))
+        e.set_W(W0), e.set_T(T0)
+        e.set_params(**kw)
+        with pytest.raises(AssertionError):
+            e.sweep(1)

@@ -41,6 +41,10 @@ CONFIGS = {
     'c4': dict(n=1000000, d=10000, k=50, scaling='strong', name='synthetic dense fp32 X 1000000x10000 k=50'),
     'c5': dict(n=100000, d=10000, k=50, scaling='weak', weighted=True,
                name='elementwise-weighted WRRI (Algorithm 10), dense fp32 X 100000x10000 k=50, 5% observed 0/1 mask'),
+    'c5s': dict(n=100000, d=10000, k=50, scaling='weak', weighted=True, sparse=True,
+                name='elementwise-weighted WRRI (Algorithm 10) 100000x10000 k=50, 5% observed 0/1 mask, SPARSE-INDEX '
+                     'formulation (fp32 residual on the observed pattern, CSR + CSC copies): a different, smaller byte '
+                     'figure than the dense c5 (SURVEY 8d)'),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
@@ -168,10 +172,30 @@ def main():
         Mask = (torch.rand(n_local, d, device=device, generator=gm) < 0.05).to(torch.float32)
         X.mul_(Mask)
         torch.cuda.synchronize()
-    eng, red, stream = make_device_shard(n_local, d, k, dtype=np.float32, device_index=local_rank, weighted=weighted)
-    eng.bind_X_device(X.data_ptr(), X.stride(0))
-    if weighted:
-        eng.bind_mask_device(Mask.data_ptr(), Mask.stride(0))
+    sparse = bool(cfg.get('sparse'))
+    eng, red, stream = make_device_shard(n_local, d, k, dtype=np.float32, device_index=local_rank,
+                                         weighted='sparse' if sparse else weighted)
+    nnz = 0
+    if sparse:
+        import scipy.sparse as sp
+        if sharded:
+            raise SystemExit('the sparse-pattern workload is single-GPU')
+        nz = Mask.nonzero()                                   # row-major order = CSR order
+        counts = torch.bincount(nz[:, 0], minlength=n_local)
+        indptr = np.concatenate([[0], np.cumsum(counts.cpu().numpy())]).astype(np.int64)
+        A = sp.csr_matrix((X[Mask > 0].cpu().numpy(), nz[:, 1].to(torch.int32).cpu().numpy(), indptr), shape=(n_local, d))
+        nnz = int(A.nnz)
+        del nz, counts
+        t_up = time.perf_counter()
+        eng.upload_observed_csr(A)
+        t_up = time.perf_counter() - t_up
+        Xs_keep, Ms_keep = X[:2000].cpu().numpy().astype(np.float64), Mask[:2000].cpu().numpy().astype(np.float64)
+        del X, Mask, A
+        torch.cuda.empty_cache()
+    else:
+        eng.bind_X_device(X.data_ptr(), X.stride(0))
+        if weighted:
+            eng.bind_mask_device(Mask.data_ptr(), Mask.stride(0))
     eng.set_W(W0)
     eng.set_T(T0)
     flags = dict(t_row_sum=1.0, reset_topic_method=None) if weighted else {}
@@ -218,6 +242,11 @@ def main():
     mask_packed = weighted and os.environ.get('RRI_MASK_BITS', '1') != '0'
     arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else 1.0
     bytes_per_launch = float(n_local) * d * 4 * arrays_per_launch
+    if sparse:
+        # per topic step and observed entry: pass B reads (index, value) of the CSR copy = 8 B; pass C reads and
+        # rewrites both copies = 2 x (4 + 4 + 4) B; two timed passes per step -> 16 B per entry and pass on average
+        # (the gathered factor tables, 32 B per row / column, are L2-resident and not counted)
+        bytes_per_launch = 16.0 * nnz
     achieved = bytes_per_launch / (pass_avg_ms * 1e-3) / 1e9 if launches else 0.0
     sweeps_per_s = args.steps / elapsed
     shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
@@ -231,21 +260,24 @@ def main():
         'config': {'workload': cfg['name'] + (' per GPU (row shard), %d x %d global' % (n_global, d)
                                               if world > 1 and cfg['scaling'] == 'weak' else ''),
                    'n_global': n_global, 'n_per_gpu': n_local, 'd': d, 'k': k,
-                   'x_storage': 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
+                   'x_storage': 'fp32 on the observed pattern (%d entries, CSR + CSC), upload %.2f s' % (nnz, t_up) if sparse else 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
                    'parallelism': 'row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step'
                                   % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2))) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                     'kernel': ('k_wpass<float,...> passes B (read E, mask) and C (read E, mask; write E), averaged; mask '
+                     'kernel': ('k_sp_seg<float,...> passes B (CSR copy: read) and C (CSR + CSC copies: read, write), '
+                                'averaged; %d observed entries' % nnz if sparse else
+                                'k_wpass<float,...> passes B (read E, mask) and C (read E, mask; write E), averaged; mask '
                                 + ('bit-packed' if mask_packed else 'fp32') if weighted
                                 else 'k_pass<float,Y,Z> (fused row-dot + column-sum pass over X)'),
                      'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},
         'sweep_level': {'global_sweeps_per_s': sweeps_per_s,
                         'timed_launch_samples': launches,
-                        'survey_formula': ('4*k*n*d*4 B per sweep (dense fp32 mask, residual not rewritten)' if weighted
+                        'survey_formula': ('32*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' if sparse
+                                           else '4*k*n*d*4 B per sweep (dense fp32 mask, residual not rewritten)' if weighted
                                            else '2*k*n*d*4 B per sweep (two BLAS2 passes per topic step)'),
-                        'algorithmic_GBps_2knd': (2.0 if not weighted else 4.0) * k * n_local * d * 4 * sweeps_per_s / 1e9,
-                        'frac_of_8TBps_2knd': (2.0 if not weighted else 4.0) * k * n_local * d * 4 * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
+                        'algorithmic_GBps_2knd': (32.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9,
+                        'frac_of_8TBps_2knd': (32.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
                         'kernel_avg_ms': {'pass': pass_avg_ms, 'wcol': wcol_ms / max(n1, 1),
                                           'trow_chain_segment': trow_ms / max(n2, 1)}},
     }
@@ -265,7 +297,10 @@ def main():
 
     if rank == 0 and world == 1 and weighted and not args.no_cpu_baseline:
         rows = min(2000, n_local)
-        Xs, Ms = X[:rows].cpu().numpy().astype(np.float64), Mask[:rows].cpu().numpy().astype(np.float64)
+        if sparse:
+            Xs, Ms = Xs_keep[:rows], Ms_keep[:rows]
+        else:
+            Xs, Ms = X[:rows].cpu().numpy().astype(np.float64), Mask[:rows].cpu().numpy().astype(np.float64)
         from oracle import rri_oracle as orc
         from threadpoolctl import threadpool_limits
         thr = int(min(16, os.cpu_count() or 16))
@@ -277,8 +312,15 @@ def main():
                                    sample='first %d of %d rows, 1 sweep (two n*d*k GEMMs per topic step), numpy float64 on %d '
                                           'threads; sample rate %.4f sweeps/s scaled by %.4g' % (rows, n_local, thr, 1.0 / dt1, rows / float(n_local)))
         from rri_nmf_amd.engine import RRIEngine
-        with RRIEngine(rows, d, k, dtype=np.float32, weighted=True, device=local_rank) as e2:
-            e2.upload_X(Xs); e2.upload_mask(Ms); e2.set_W(W0[:rows]); e2.set_T(T0); e2.set_params(**flags)
+        with RRIEngine(rows, d, k, dtype=np.float32, weighted='sparse' if sparse else True, device=local_rank) as e2:
+            if sparse:
+                import scipy.sparse as sp
+                As = sp.csr_matrix(Ms)
+                As.data = Xs[Ms > 0]
+                e2.upload_observed_csr(As)
+            else:
+                e2.upload_X(Xs); e2.upload_mask(Ms)
+            e2.set_W(W0[:rows]); e2.set_T(T0); e2.set_params(**flags)
             e2.sweep(1)
             Wg, Tg = e2.get_W(), e2.get_T()
         rec = lambda W_, T_: Ms * (W_ @ T_)

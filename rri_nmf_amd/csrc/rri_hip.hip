@@ -77,12 +77,22 @@ struct rri_ctx {
     // weighted flavour on a CSR observation pattern (rri_upload_observed_csr): no dense n x d array at all
     bool sparse = false;
     i64 nnz = 0;
-    int sp_max_row = 0, sp_lps_row = 64, sp_lps_col = 64, kp = 8;
-    i64 *sp_rowptr = nullptr, *sp_colptr = nullptr;
-    int *sp_col = nullptr, *sp_row = nullptr, *sp_perm = nullptr;
-    void *sp_x = nullptr, *sp_e = nullptr, *sp_ec = nullptr;   // values on the pattern: X, residual (CSR), residual (CSC)
-    SpGather *sp_gd = nullptr, *sp_gn = nullptr;               // packed gather tables over the columns / the rows
-    double* sp_Tt = nullptr;                                   // T transposed, d x kp
+    int sp_max_row = 0, kp = 8;
+    i64* sp_rowptr = nullptr;   // canonical CSR of the pattern with X on it: residual rebuild, objective, resets
+    int* sp_col = nullptr;
+    void *sp_x = nullptr, *sp_e = nullptr;
+    double* sp_Tt = nullptr;    // T transposed, d x kp
+    // the two blocked copies of the residual (rri_sparse_kernels.hpp): [0] rows as segments, cut into column
+    // blocks; [1] columns as segments, cut into row blocks
+    struct SpCopy {
+        int nblk = 1, bw = 1, lps = 64, nwork = 0;
+        i64 nseg = 0, gdim = 0, count = 0;   // count: entries incl. the padding of every segment to a multiple of 4
+        i64* segptr = nullptr;          // [nblk][nseg + 1]
+        unsigned short* idx = nullptr;  // offset inside the block
+        void* val = nullptr;
+        int* perm = nullptr;            // position in the canonical CSR
+        SpWork* work = nullptr;
+    } sp[2];
     bool resid_fresh = false;   // weighted: E was rebuilt and no half step has run since
     bool dt_pending = false;    // weighted: dtv holds a T-row change that E does not contain yet
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
@@ -272,43 +282,42 @@ struct LaunchX {
         }
     }
     // ---- sparse pattern (rri_sparse_kernels.hpp) ----------------------------------------------------
-    static void sp_pack(rri_ctx* c, const double* B1, const double* B2, const double* V, i64 m, SpGather* G) {
-        hipLaunchKernelGGL(k_sp_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, B1, B2, V, m, G,
-                           (const DevState*)c->st);
+    template <bool DO_S, bool UPD2, bool WRITE, int LPS>
+    static void sp_blk_k(rri_ctx* c, const rri_ctx::SpCopy& cp, const double* B1, const double* B2, const double* V,
+                         const double* A1, const double* A2, double* S1, double* S2, i64 lds) {
+        typedef typename SpTab<SX>::type TF;
+        const size_t sh = 3 * (size_t)cp.bw * sizeof(TF);
+        static bool attr_set = false;   // per instantiation
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_sp_blk<SX, DO_S, UPD2, WRITE, LPS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SP_BLOCK_BYTES);
+            attr_set = true;
+        }
+        if (cp.nwork < 1) return;
+        hipLaunchKernelGGL((k_sp_blk<SX, DO_S, UPD2, WRITE, LPS>), dim3(cp.nwork), dim3(1024), sh, c->stream,
+                           (const SpWork*)cp.work, (const i64*)cp.segptr, cp.nseg, (const unsigned short*)cp.idx,
+                           (SX*)cp.val, cp.bw, cp.gdim, B1, B2, V, A1, A2, S1, S2, lds, (const DevState*)c->st);
     }
     template <bool DO_S, bool UPD2, bool WRITE>
-    static void sp_seg(rri_ctx* c, bool csc, const double* A1, const double* A2, double* S1, double* S2) {
-        const i64 nseg = csc ? c->d : c->n;
-        const int lps = csc ? c->sp_lps_col : c->sp_lps_row;
-        const i64* ptr = csc ? c->sp_colptr : c->sp_rowptr;
-        const int* idx = csc ? c->sp_row : c->sp_col;
-        SX* val = (SX*)(csc ? c->sp_ec : c->sp_e);
-        const SpGather* G = csc ? c->sp_gn : c->sp_gd;
-        const unsigned nb = (unsigned)((nseg * lps + 255) / 256);
-#define RRI_SEG(LPS_)                                                                                              \
-    hipLaunchKernelGGL((k_sp_seg<SX, DO_S, UPD2, WRITE, LPS_>), dim3(nb), dim3(256), 0, c->stream, ptr, idx, val, nseg, \
-                       A1, A2, G, S1, S2, (const DevState*)c->st)
-        switch (lps) {
-            case 8: RRI_SEG(8); break;
-            case 16: RRI_SEG(16); break;
-            case 32: RRI_SEG(32); break;
-            default: RRI_SEG(64); break;
+    static void sp_blk(rri_ctx* c, int which, const double* B1, const double* B2, const double* V, const double* A1,
+                       const double* A2, double* S1, double* S2, i64 lds) {
+        const rri_ctx::SpCopy& cp = c->sp[which];
+        switch (cp.lps) {
+            case 8: sp_blk_k<DO_S, UPD2, WRITE, 8>(c, cp, B1, B2, V, A1, A2, S1, S2, lds); break;
+            case 16: sp_blk_k<DO_S, UPD2, WRITE, 16>(c, cp, B1, B2, V, A1, A2, S1, S2, lds); break;
+            case 32: sp_blk_k<DO_S, UPD2, WRITE, 32>(c, cp, B1, B2, V, A1, A2, S1, S2, lds); break;
+            default: sp_blk_k<DO_S, UPD2, WRITE, 64>(c, cp, B1, B2, V, A1, A2, S1, S2, lds); break;
         }
-#undef RRI_SEG
     }
-    // the same operation as wpass on the two copies of the pattern residual: row products from the CSR copy
-    // (into Ypart / Y2part, one "panel"), column sums from the CSC copy (straight into red = [a | nw])
+    // the same operation as wpass on the two copies of the pattern residual: row products from the row copy
+    // (one Ypart "panel" per column block), column sums from the column copy (one Zpart row per row block)
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
     static void sp_wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                          const double* a2, const double* b2) {
-        if (DO_Y || WRITE) {
-            sp_pack(c, b1, UPD2 ? b2 : nullptr, DO_Y ? trow : nullptr, c->d, c->sp_gd);
-            sp_seg<DO_Y, UPD2, WRITE>(c, false, a1, a2, c->Ypart, c->Y2part);
-        }
-        if (DO_Z || WRITE) {
-            sp_pack(c, a1, UPD2 ? a2 : nullptr, DO_Z ? wc : nullptr, c->n, c->sp_gn);
-            sp_seg<DO_Z, UPD2, WRITE>(c, true, b1, b2, c->red, c->red + c->LD);
-        }
+        if (DO_Y || WRITE)   // segments = rows (factors a1, a2), gathered = columns (b1, b2, trow)
+            sp_blk<DO_Y, UPD2, WRITE>(c, 0, b1, b2, trow, a1, a2, c->Ypart, c->Y2part, c->n);
+        if (DO_Z || WRITE)   // segments = columns (b1, b2), gathered = rows (a1, a2, wc)
+            sp_blk<DO_Z, UPD2, WRITE>(c, 1, a1, a2, wc, b1, b2, c->Zpart, c->Z2part, c->LD);
     }
     static void sp_resid(rri_ctx* c, bool write_e, double* rowobj, double* rowpos) {
         const i64 total = (i64)c->k * c->d;
@@ -319,8 +328,9 @@ struct LaunchX {
                            (const double*)c->W, c->ldw, (const double*)c->sp_Tt, c->k, c->kp,
                            write_e ? (SX*)c->sp_e : (SX*)nullptr, rowobj, rowpos);
         if (write_e && c->nnz > 0)
-            hipLaunchKernelGGL((k_sp_permute<SX>), dim3(2048), dim3(256), 0, c->stream, (const SX*)c->sp_e,
-                               (const int*)c->sp_perm, c->nnz, (SX*)c->sp_ec);
+            for (int w = 0; w < 2; ++w)
+                hipLaunchKernelGGL((k_sp_permute<SX>), dim3(2048), dim3(256), 0, c->stream, (const SX*)c->sp_e,
+                                   (const int*)c->sp[w].perm, c->sp[w].count, (SX*)c->sp[w].val);
     }
     // 0/1 masks are bit-packed (32 columns per word): the mask then costs 1/32 of its fp32 bytes per pass
     static rri_status pack_mask_if_binary(rri_ctx* c) {
@@ -648,7 +658,6 @@ void w_refresh(rri_ctx* c) {
 }
 
 void w_reduce(rri_ctx* c) {
-    if (c->sparse) return;   // the CSC pass leaves the column sums in red itself
     const int nb = (int)((c->LD + 31) / 32);
     hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
                        (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
@@ -866,7 +875,20 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     rpb = std::min<i64>(round_up(rpb, 16), rpb_cap);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);
-    if (c->sparse) { c->npanels = 1; c->nrb = 1; }   // no dense pass: row products / column sums arrive complete
+    if (c->sparse) {
+        // no dense pass: the row copy is cut into column blocks (= Ypart panels), the column copy into row blocks
+        // (= Zpart rows); block widths so that three factor tables of a block fit SP_BLOCK_BYTES of LDS
+        const i64 cap = SP_BLOCK_BYTES / (3 * (dtype == RRI_F32 ? 4 : 8));
+        for (int w = 0; w < 2; ++w) {
+            rri_ctx::SpCopy& cp = c->sp[w];
+            cp.gdim = w == 0 ? d : n;
+            cp.nseg = w == 0 ? n : d;
+            cp.nblk = (int)((cp.gdim + cap - 1) / cap);
+            cp.bw = (int)round_up((cp.gdim + cp.nblk - 1) / cp.nblk, 64);
+        }
+        c->npanels = c->sp[0].nblk;
+        c->nrb = c->sp[1].nblk;
+    }
     c->nwb = (int)((n + 64 * WCOL_TILES - 1) / (64 * WCOL_TILES));   // k_wcol blocks = rows of Gpart
     c->nwb256 = (int)((n + 255) / 256);
     c->ntb = (int)((d + 127) / 128);
@@ -901,9 +923,16 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->itmp, 16 * sizeof(i64)));
     if (weighted) {
         const i64 zn = std::max<i64>(c->LD, n);
-        if (!c->sparse) CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+        if (!c->sparse) {
+            CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+            // k_resid writes the d real columns only; the passes stream all LD: the pad columns must hold zeros
+            // (recycled memory there once held NaN patterns, which fmax(numer, 0) turned into zero rows of W)
+            if (c->LD != d) CR(hipMemsetAsync(c->E, 0, (size_t)n * c->LD * es_x, c->stream));
+        }
         CR(hipMalloc((void**)&c->Y2part, (size_t)c->npanels * n * f8));
+        CR(hipMemsetAsync(c->Y2part, 0, (size_t)c->npanels * n * f8, c->stream));
         CR(hipMalloc((void**)&c->Z2part, (size_t)c->nrb * c->LD * f8));
+        CR(hipMemsetAsync(c->Z2part, 0, (size_t)c->nrb * c->LD * f8, c->stream));
         CR(hipMalloc((void**)&c->dtv, (size_t)c->LD * f8));
         CR(hipMalloc((void**)&c->dwv, (size_t)n * f8));
         CR(hipMalloc((void**)&c->wold, (size_t)n * f8));
@@ -911,8 +940,6 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         CR(hipMemsetAsync(c->zeros, 0, (size_t)zn * f8, c->stream));
         CR(hipMemsetAsync(c->dtv, 0, (size_t)c->LD * f8, c->stream));
         if (c->sparse) {
-            CR(hipMalloc((void**)&c->sp_gd, (size_t)d * sizeof(SpGather)));
-            CR(hipMalloc((void**)&c->sp_gn, (size_t)n * sizeof(SpGather)));
             CR(hipMalloc((void**)&c->sp_Tt, (size_t)d * c->kp * f8));
             CR(hipMemsetAsync(c->sp_Tt, 0, (size_t)d * c->kp * f8, c->stream));
         }
@@ -938,8 +965,9 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->sp_rowptr, (void*)c->sp_colptr, (void*)c->sp_col, (void*)c->sp_row, (void*)c->sp_perm, c->sp_x,
-                    c->sp_e, c->sp_ec, (void*)c->sp_gd, (void*)c->sp_gn, (void*)c->sp_Tt};
+                    (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
+                    (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -1086,43 +1114,21 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
     CsrDev dv;   // validates the arrays; its device copies of indptr / indices become the CSR copy
     rri_status s = csr_to_device(c, indptr, indices, values, nnz, data_dtype, dv);
     if (s != RRI_OK) return s;
-    // column-major copy of the pattern: counting sort on the host (stable: rows ascend inside a column)
-    std::vector<i64> colptr((size_t)c->d + 1, 0);
-    for (i64 p = 0; p < nnz; ++p) colptr[(size_t)indices[p] + 1] += 1;
-    i64 longest_col = 0;
-    for (i64 j = 0; j < c->d; ++j) {
-        longest_col = std::max(longest_col, colptr[(size_t)j + 1]);
-        colptr[(size_t)j + 1] += colptr[(size_t)j];
-    }
-    std::vector<int> rowidx((size_t)std::max<i64>(nnz, 1)), perm((size_t)std::max<i64>(nnz, 1));
-    {
-        std::vector<i64> fill(colptr.begin(), colptr.end() - 1);
-        for (i64 r = 0; r < c->n; ++r)
-            for (i64 p = indptr[r]; p < indptr[r + 1]; ++p) {
-                const i64 q = fill[(size_t)indices[p]]++;
-                rowidx[(size_t)q] = (int)r;
-                perm[(size_t)q] = (int)p;
-            }
-    }
+    for (i64 r = 0; r < c->n; ++r)
+        for (i64 p = indptr[r] + 1; p < indptr[r + 1]; ++p)
+            if (indices[p] <= indices[p - 1])
+                return fail(c, RRI_ERR_INVALID, "column indices of row %lld are not strictly increasing", r);
     i64 longest_row = 0;
     for (i64 r = 0; r < c->n; ++r) longest_row = std::max<i64>(longest_row, (i64)(indptr[r + 1] - indptr[r]));
-    void* old[] = {(void*)c->sp_rowptr, (void*)c->sp_colptr, (void*)c->sp_col, (void*)c->sp_row, (void*)c->sp_perm,
-                   c->sp_x, c->sp_e, c->sp_ec};
+    void* old[] = {(void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e};
     for (void* b : old)
         if (b) (void)hipFree(b);
     c->sp_rowptr = dv.indptr; dv.indptr = nullptr;
     c->sp_col = dv.indices; dv.indices = nullptr;
-    c->sp_colptr = nullptr; c->sp_row = nullptr; c->sp_perm = nullptr; c->sp_x = nullptr; c->sp_e = nullptr; c->sp_ec = nullptr;
+    c->sp_x = nullptr; c->sp_e = nullptr;
     const size_t cnt = (size_t)std::max<i64>(nnz, 1);
-    HIPCHK(c, hipMalloc((void**)&c->sp_colptr, (size_t)(c->d + 1) * sizeof(i64)));
-    HIPCHK(c, hipMalloc((void**)&c->sp_row, cnt * sizeof(int)));
-    HIPCHK(c, hipMalloc((void**)&c->sp_perm, cnt * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->sp_x, cnt * c->es));
     HIPCHK(c, hipMalloc(&c->sp_e, cnt * c->es));
-    HIPCHK(c, hipMalloc(&c->sp_ec, cnt * c->es));
-    HIPCHK(c, hipMemcpyAsync(c->sp_colptr, colptr.data(), (size_t)(c->d + 1) * sizeof(i64), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sp_row, rowidx.data(), cnt * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sp_perm, perm.data(), cnt * sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (nnz > 0) {   // values -> storage type (dv.data holds them in the caller's type)
         const bool hf = data_dtype == RRI_F32, df = c->dtype == RRI_F32;
         if (hf && df) launch_convert<float, float, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
@@ -1130,18 +1136,89 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
         else if (df) launch_convert<double, float, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
         else launch_convert<double, double, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
     }
+    // the two blocked copies: counting sort on the host, stable, so offsets ascend inside a segment
+    int target_items = 3 * 256;
+    if (const char* e = getenv("RRI_SP_ITEMS")) target_items = std::max(1, atoi(e));
+    for (int w = 0; w < 2; ++w) {
+        rri_ctx::SpCopy& cp = c->sp[w];
+        void* oldc[] = {(void*)cp.segptr, (void*)cp.idx, cp.val, (void*)cp.perm, (void*)cp.work};
+        for (void* b : oldc)
+            if (b) (void)hipFree(b);
+        cp.segptr = nullptr; cp.idx = nullptr; cp.val = nullptr; cp.perm = nullptr; cp.work = nullptr;
+        const i64 nseg = cp.nseg, stride = nseg + 1;
+        std::vector<i64> sp((size_t)cp.nblk * stride, 0);
+        // count: entry (r, j) lives in block (gather index / bw), segment (the other index)
+        for (i64 r = 0; r < c->n; ++r)
+            for (i64 p = indptr[r]; p < indptr[r + 1]; ++p) {
+                const i64 j = indices[p];
+                const i64 g = w == 0 ? j : r, sgm = w == 0 ? r : j;
+                sp[(size_t)((g / cp.bw) * stride + sgm + 1)] += 1;
+            }
+        i64 run = 0;   // exclusive prefix over (block, segment); every block row keeps nseg + 1 pointers.
+        // Segments are padded to multiples of 4 entries (k_sp_blk moves quads).
+        for (int b = 0; b < cp.nblk; ++b) {
+            i64* row = sp.data() + (size_t)b * stride;
+            row[0] = run;
+            for (i64 q = 1; q <= nseg; ++q) {
+                run += (row[q] + 3) / 4 * 4;
+                row[q] = run;
+            }
+        }
+        cp.count = run;
+        const size_t cntp = (size_t)std::max<i64>(run, 4);
+        std::vector<unsigned short> bidx(cntp, SP_PAD);
+        std::vector<int> perm(cntp, -1);
+        {
+            std::vector<i64> fill((size_t)cp.nblk * nseg);
+            for (int b = 0; b < cp.nblk; ++b)
+                for (i64 q = 0; q < nseg; ++q) fill[(size_t)b * nseg + q] = sp[(size_t)b * stride + q];
+            for (i64 r = 0; r < c->n; ++r)
+                for (i64 p = indptr[r]; p < indptr[r + 1]; ++p) {
+                    const i64 j = indices[p];
+                    const i64 g = w == 0 ? j : r, sgm = w == 0 ? r : j;
+                    const i64 b = g / cp.bw;
+                    const i64 q = fill[(size_t)(b * nseg + sgm)]++;
+                    bidx[(size_t)q] = (unsigned short)(g - b * cp.bw);
+                    perm[(size_t)q] = (int)p;
+                }
+        }
+        // work items: runs of segments of one block holding about nnz / target_items entries (at most 8192 segments)
+        std::vector<SpWork> work;
+        const i64 per_item = std::max<i64>(4096, nnz / target_items);
+        for (int b = 0; b < cp.nblk; ++b) {
+            const i64* row = sp.data() + (size_t)b * stride;
+            i64 s0 = 0;
+            while (s0 < nseg) {
+                i64 s1 = s0 + 1;
+                while (s1 < nseg && s1 - s0 < 8192 && row[s1 + 1] - row[s0] <= per_item) ++s1;
+                work.push_back(SpWork{b, (int)s0, (int)s1, 0});
+                s0 = s1;
+            }
+        }
+        cp.nwork = (int)work.size();
+        // lanes per segment: 4 quads of 4 entries per lane and iteration
+        const i64 avg = nnz / std::max<i64>(1, (i64)cp.nblk * nseg);
+        cp.lps = avg >= 768 ? 64 : avg >= 384 ? 32 : avg >= 192 ? 16 : 8;
+        if (const char* e = getenv(w == 0 ? "RRI_SP_LANES_ROW" : "RRI_SP_LANES_COL")) {
+            const int v = atoi(e);
+            if (v == 8 || v == 16 || v == 32 || v == 64) cp.lps = v;
+        }
+        HIPCHK(c, hipMalloc((void**)&cp.segptr, sp.size() * sizeof(i64)));
+        HIPCHK(c, hipMalloc((void**)&cp.idx, cntp * sizeof(unsigned short)));
+        HIPCHK(c, hipMalloc(&cp.val, cntp * c->es));
+        HIPCHK(c, hipMemsetAsync(cp.val, 0, cntp * c->es, c->stream));
+        HIPCHK(c, hipMalloc((void**)&cp.perm, cntp * sizeof(int)));
+        HIPCHK(c, hipMalloc((void**)&cp.work, std::max<size_t>(1, work.size()) * sizeof(SpWork)));
+        HIPCHK(c, hipMemcpyAsync(cp.segptr, sp.data(), sp.size() * sizeof(i64), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(cp.idx, bidx.data(), cntp * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(cp.perm, perm.data(), cntp * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (!work.empty())
+            HIPCHK(c, hipMemcpyAsync(cp.work, work.data(), work.size() * sizeof(SpWork), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // the host vectors go out of scope
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nnz = nnz;
     c->sp_max_row = (int)longest_row;
-    auto lanes_for = [](i64 entries, i64 segments) {
-        const i64 avg = segments > 0 ? entries / segments : 0;
-        return avg >= 128 ? 64 : avg >= 64 ? 32 : avg >= 32 ? 16 : 8;
-    };
-    c->sp_lps_row = lanes_for(nnz, c->n);
-    c->sp_lps_col = lanes_for(nnz, c->d);
-    if (const char* e = getenv("RRI_SP_LANES_ROW")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) c->sp_lps_row = v; }
-    if (const char* e = getenv("RRI_SP_LANES_COL")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) c->sp_lps_col = v; }
-    (void)longest_col;
     c->have_X = true;
     c->have_M = true;
     invalidate(c);
@@ -1556,6 +1633,7 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
     if (r != RRI_OK) return r;
     if (c->prm.fix_W || c->prm.fix_T || c->k < 2)
         return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping needs k >= 2 and both halves free");
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping is not available for sparse-pattern handles");
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->weighted) {

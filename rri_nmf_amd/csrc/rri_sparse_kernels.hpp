@@ -9,35 +9,33 @@
 // Both copies take every rank-one correction e' = e - (a1_i b1_j + a2_i b2_j) with the same operations in
 // the same order, so they stay bit-identical and every sum has a fixed order (no atomics).  One kernel serves
 // both orientations: a "segment" is a row of the CSR copy or a column of the CSC copy, the per-segment factors
-// come from one vector pair, the per-entry factors are gathered through the index array from a packed table
-// {B1, B2, V, -} (one 32-byte gather per entry instead of three 8-byte ones).
+// come from one vector pair, the per-entry factors from LDS tables (k_sp_blk below; gathering them from L2
+// instead ran at 1.3-1.7 TB/s of index / value traffic, bound by L2 sector bandwidth).
 //
-// Bytes per observed entry and topic step (fp32 values, int32 indices): pass B 8 (CSR read), pass C 12 + 12
-// (read + write of both copies) = 32 B, against 12.25 B per DENSE entry of the bit-packed dense schedule:
-// the sparse formulation moves fewer bytes below ~38 % density (at the 5 % of BASELINE config 5: 7.6x fewer).
+// Bytes per observed entry and topic step (fp32 values, uint16 block offsets): pass B 6 (CSR read), pass C
+// 10 + 10 (read + write of both copies) = 26 B, against 12.25 B per DENSE entry of the bit-packed dense
+// schedule: the sparse formulation moves fewer bytes below ~47 % density (at the 5 % of BASELINE config 5: 9x).
 #pragma once
 #include "rri_kernels.hpp"
 
 namespace rri {
 
-struct __attribute__((aligned(32))) SpGather { double b1, b2, v, pad; };
+// Blocked segment store.  A copy of the pattern is cut into blocks along its GATHER dimension (column blocks
+// of the CSR copy, row blocks of the CSC copy), at most SP_BLOCK_BYTES / (3 * sizeof(TF)) wide, so that the three
+// factor vectors an entry needs {b1, b2, v}[gather index] sit in LDS for the whole block (10240 entries of fp32
+// factors for an fp32 handle, 5120 of fp64 for an fp64 handle) and the per-entry index is a uint16 offset into
+// the block.  Entries are ordered (block, segment, offset); segptr[block][segment] delimits them.  The sums of a
+// segment come out per block -- S[block][segment] -- and the consumers that already add row-dot panels
+// (k_wwcol) or row-block partials (k_reduce) add the blocks in a fixed order.
+//
+// Factors are rounded to the table type TF on BOTH sides (the per-segment scalars too), so the CSR and the CSC
+// copy apply bit-identical corrections; for an fp32 handle that is the rounding the stored residual has anyway.
+constexpr int SP_BLOCK_BYTES = 120 * 1024;
+template <typename SX> struct SpTab { typedef float type; };
+template <> struct SpTab<double> { typedef double type; };
 
-// G[g] = {B1[g], B2[g], V[g]}; NULL vectors read as 0
-__global__ __launch_bounds__(256) void k_sp_pack(const double* __restrict__ B1, const double* __restrict__ B2,
-                                                 const double* __restrict__ V, i64 m, SpGather* __restrict__ G,
-                                                 const DevState* __restrict__ st) {
-    if (st->halt) return;
-    const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (g >= m) return;
-    SpGather o;
-    o.b1 = B1 ? B1[g] : 0.0;
-    o.b2 = B2 ? B2[g] : 0.0;
-    o.v = V ? V[g] : 0.0;
-    o.pad = 0.0;
-    G[g] = o;
-}
+struct SpWork { int blk, s0, s1, pad; };   // one workgroup: segments [s0, s1) of block blk
 
-// sum over the LPS lanes (a power of two <= 64) of a segment group; every lane of the group gets the total
 template <int LPS>
 __device__ __forceinline__ double group_sum(double v) {
 #pragma unroll
@@ -45,65 +43,100 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
-// One segment (row of the CSR copy / column of the CSC copy) per group of LPS lanes, 4 entries per lane in flight.
-//   e' = e - (A1[s] * G[g].b1 + [UPD2] A2[s] * G[g].b2)        g = idx[p]
+//   e' = e - (A1[s] * B1[g] + [UPD2] A2[s] * B2[g])            g = block offset + idx[p]
 //   WRITE: val[p] = e' (rounded to the storage type; the sums then use the stored value, as the dense pass does)
-//   DO_S : S1[s] = sum e' * G[g].v ,  S2[s] = sum G[g].v^2
+//   DO_S : S1[blk][s] = sum e' * V[g] ,  S2[blk][s] = sum V[g]^2
+// Every segment is padded to a multiple of 4 entries (pad offset SP_PAD), so a lane moves 4 consecutive entries
+// per load: 8 bytes of offsets + 16 (fp32) / 32 (fp64) bytes of values, 4 such quads in flight per lane -- about
+// 6 KB of reads in flight per wave; with one entry per load the passes ran at a third of the bandwidth, bound by
+// the round trips of too few bytes in flight.  One segment per group of LPS lanes; 1024 threads share the tables.
+constexpr unsigned short SP_PAD = 0xFFFF;
+template <typename SX> struct SpQuad;
+template <> struct SpQuad<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct SpQuad<double> { typedef double type __attribute__((ext_vector_type(4))); };
+typedef unsigned short sp_us4 __attribute__((ext_vector_type(4)));
+
 template <typename SX, bool DO_S, bool UPD2, bool WRITE, int LPS>
-__global__ __launch_bounds__(256) void k_sp_seg(const i64* __restrict__ ptr, const int* __restrict__ idx,
-                                                SX* __restrict__ val, i64 nseg, const double* __restrict__ A1,
-                                                const double* __restrict__ A2, const SpGather* __restrict__ G,
-                                                double* __restrict__ S1, double* __restrict__ S2,
-                                                const DevState* __restrict__ st) {
+__global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work, const i64* __restrict__ segptr,
+                                                 i64 nseg, const unsigned short* __restrict__ idx,
+                                                 SX* __restrict__ val, int bw, i64 gdim,
+                                                 const double* __restrict__ B1, const double* __restrict__ B2,
+                                                 const double* __restrict__ V, const double* __restrict__ A1,
+                                                 const double* __restrict__ A2, double* __restrict__ S1,
+                                                 double* __restrict__ S2, i64 lds, const DevState* __restrict__ st) {
+    typedef typename SpTab<SX>::type TF;
+    typedef typename SpQuad<SX>::type V4;
     if (st->halt) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TF* tb1 = reinterpret_cast<TF*>(smem);   // [bw]
+    TF* tb2 = tb1 + bw;                      // [bw]
+    TF* tv = tb2 + bw;                       // [bw]
+    const SpWork w = work[blockIdx.x];
+    const i64 g0 = (i64)w.blk * bw;
+    for (int g = threadIdx.x; g < bw; g += 1024) {
+        const bool in = g0 + g < gdim;
+        tb1[g] = in ? (TF)B1[g0 + g] : TF(0);
+        if (UPD2) tb2[g] = in ? (TF)B2[g0 + g] : TF(0);
+        if (DO_S) tv[g] = in ? (TF)V[g0 + g] : TF(0);
+    }
+    __syncthreads();
     constexpr int UNR = 4;
-    const int sub = threadIdx.x % LPS;
-    const i64 seg = ((i64)blockIdx.x * 256 + threadIdx.x) / LPS;
-    i64 p0 = 0, p1 = 0;
-    double c1 = 0.0, c2 = 0.0;
-    if (seg < nseg) {
-        p0 = ptr[seg];
-        p1 = ptr[seg + 1];
-        c1 = A1[seg];
-        if (UPD2) c2 = A2[seg];
-    }
-    double s1 = 0.0, s2 = 0.0;
-    for (i64 p = p0 + sub; p < p1; p += (i64)LPS * UNR) {
-        int g[UNR];
-        SX e[UNR];
+    constexpr int GROUPS = 1024 / LPS;
+    const int sub = threadIdx.x % LPS, grp = threadIdx.x / LPS;
+    const i64* sp = segptr + (i64)w.blk * (nseg + 1);
+    const sp_us4* idx4 = reinterpret_cast<const sp_us4*>(idx);
+    V4* val4 = reinterpret_cast<V4*>(val);
+    for (int s = w.s0 + grp; s < w.s1; s += GROUPS) {
+        const i64 q0 = sp[s] >> 2, q1 = sp[s + 1] >> 2;     // in quads: segment bounds are multiples of 4
+        const double c1 = (double)(TF)A1[s];
+        const double c2 = UPD2 ? (double)(TF)A2[s] : 0.0;
+        double s1 = 0.0, s2 = 0.0;
+        for (i64 q = q0 + sub; q < q1; q += (i64)LPS * UNR) {
+            sp_us4 g[UNR];
+            V4 e[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const i64 q = p + (i64)u * LPS;
-            const bool ok = q < p1;
-            g[u] = ok ? __builtin_nontemporal_load(idx + q) : -1;
-            e[u] = ok ? __builtin_nontemporal_load(val + q) : SX(0);
-        }
-        SpGather t[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (g[u] >= 0) t[u] = G[g[u]];
-            else { t[u].b1 = 0.0; t[u].b2 = 0.0; t[u].v = 0.0; t[u].pad = 0.0; }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            double corr = c1 * t[u].b1;
-            if (UPD2) corr = fma(c2, t[u].b2, corr);
-            double x = (double)e[u] - corr;
-            if (WRITE) {
-                const SX r = (SX)x;
-                if (g[u] >= 0) __builtin_nontemporal_store(r, val + p + (i64)u * LPS);
-                x = (double)r;
+            for (int u = 0; u < UNR; ++u) {
+                const i64 qq = q + (i64)u * LPS;
+                if (qq < q1) {
+                    g[u] = __builtin_nontemporal_load(idx4 + qq);
+                    e[u] = __builtin_nontemporal_load(val4 + qq);
+                } else {
+                    g[u] = sp_us4{SP_PAD, SP_PAD, SP_PAD, SP_PAD};
+                    e[u] = V4{SX(0), SX(0), SX(0), SX(0)};
+                }
             }
-            if (DO_S && g[u] >= 0) {
-                s1 = fma(x, t[u].v, s1);
-                s2 = fma(t[u].v, t[u].v, s2);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                V4 out = e[u];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int gi = g[u][m];
+                    if (gi == SP_PAD) continue;
+                    double corr = c1 * (double)tb1[gi];
+                    if (UPD2) corr = fma(c2, (double)tb2[gi], corr);
+                    double x = (double)e[u][m] - corr;
+                    if (WRITE) {
+                        const SX r = (SX)x;
+                        out[m] = r;
+                        x = (double)r;
+                    }
+                    if (DO_S) {
+                        const double v = (double)tv[gi];
+                        s1 = fma(x, v, s1);
+                        s2 = fma(v, v, s2);
+                    }
+                }
+                if (WRITE) {
+                    const i64 qq = q + (i64)u * LPS;
+                    if (qq < q1) __builtin_nontemporal_store(out, val4 + qq);
+                }
             }
         }
-    }
-    if (DO_S) {
-        s1 = group_sum<LPS>(s1);
-        s2 = group_sum<LPS>(s2);
-        if (sub == 0 && seg < nseg) { S1[seg] = s1; S2[seg] = s2; }
+        if (DO_S) {
+            s1 = group_sum<LPS>(s1);
+            s2 = group_sum<LPS>(s2);
+            if (sub == 0) { S1[(i64)w.blk * lds + s] = s1; S2[(i64)w.blk * lds + s] = s2; }
+        }
     }
 }
 
@@ -165,11 +198,14 @@ __global__ __launch_bounds__(256) void k_sp_resid(const i64* __restrict__ rowptr
     }
 }
 
-// the CSC copy of the residual after a refresh: ec[p] = e[perm[p]]
+// a blocked copy of the residual after a refresh: out[q] = e[perm[q]] (perm < 0: padding of a segment, kept 0)
 template <typename SX>
-__global__ __launch_bounds__(256) void k_sp_permute(const SX* __restrict__ e, const int* __restrict__ perm, i64 nnz,
-                                                    SX* __restrict__ ec) {
-    for (i64 p = (i64)blockIdx.x * 256 + threadIdx.x; p < nnz; p += (i64)gridDim.x * 256) ec[p] = e[perm[p]];
+__global__ __launch_bounds__(256) void k_sp_permute(const SX* __restrict__ e, const int* __restrict__ perm, i64 count,
+                                                    SX* __restrict__ out) {
+    for (i64 q = (i64)blockIdx.x * 256 + threadIdx.x; q < count; q += (i64)gridDim.x * 256) {
+        const int p = perm[q];
+        out[q] = p >= 0 ? e[p] : SX(0);
+    }
 }
 
 // the reset row max(X[mi,:] - W[mi,:] T, 0) (nmf.py:770-775) from the pattern of row mi = *row_idx; out has d

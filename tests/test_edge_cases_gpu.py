@@ -82,3 +82,30 @@ def test_same_outcome_as_oracle(name):
     X, k, W0, T0, kw = CASES[name]()
     a, b = both(X, k, W0, T0, **kw)
     agree(a, b)
+
+
+def test_ragged_d_weighted_on_recycled_memory():
+    """d not a multiple of the 16-byte vector: the pad column of the maintained residual is streamed by the passes
+    and must hold zeros whatever the allocator hands out (a NaN pattern there once zeroed rows of W)"""
+    import torch
+    from rri_nmf_amd.engine import RRIEngine
+    from oracle import rri_oracle as orc
+    n, d, k = 412, 187, 5
+    rs = np.random.RandomState(0)
+    M = (rs.rand(n, d) < 0.2).astype(np.float64)
+    X = rs.rand(n, d) * M
+    W0, T0 = rnd(1, n, k), rnd(2, k, d)
+    kw = dict(t_row_sum=1.0, reset_topic_method=None)
+    ref = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), W_mat=M, max_iter=2, eps_stop=-1, **kw)
+    for store in (np.float64, np.float32):
+        for _ in range(2):
+            junk = torch.full((n * (d + 8),), float('nan'), dtype=torch.float64, device='cuda')   # poison, then free
+            del junk
+            torch.cuda.empty_cache()
+            with RRIEngine(n, d, k, dtype=store, weighted=True) as e:
+                e.upload_X(X.astype(store)), e.upload_mask(M.astype(store))
+                e.set_W(W0), e.set_T(T0)
+                e.set_params(**kw)
+                e.sweep(2)
+                tol = 1e-9 if store == np.float64 else 1e-4
+                assert relfro(e.get_W(), ref['W']) < tol and relfro(e.get_T(), ref['T']) < tol

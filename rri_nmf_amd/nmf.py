@@ -9,6 +9,8 @@ additions select the device side:
     device_init  True / False: run the products of the randomized SVD behind the NNDSVD initialisations on the
             device (initialization.randomized_svd_device) or in scikit-learn on the host; None = on the device from
             2e7 entries of X on.  Same algorithm either way.
+    sparse_pattern  weighted flavour with scipy sparse X and 0/1 sparse W_mat: keep the residual on the observed
+            entries only (True), densify on the device (False); None = pattern-only below 35 % observed.
 
 What runs where
     host (numpy, once):   argument checks, warnings and sentinel returns (nmf.py:280-315), the
@@ -41,21 +43,21 @@ class TrueObjComputer(object):
     """Handle returned as rtv['obj_calculator'] (nmf.py:58-94): remembers the problem and the last
     objective value; true_objective() re-evaluates it on the device."""
 
-    def __init__(self, X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, Wm, wr, dtype=None, device=0):
+    def __init__(self, X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, Wm, wr, dtype=None, device=0,
+                 sparse_pattern=None):
         self.X, self.W, self.T = X, W, T
         self.reg_w_l2, self.reg_t_l2 = reg_w_l2, reg_t_l2
         self.reg_w_l1, self.reg_t_l1 = reg_w_l1, reg_t_l1
         self.Wm, self.wr = Wm, wr
         self.obj = np.inf
-        self._dtype, self._device = dtype, device
+        self._dtype, self._device, self._sparse_pattern = dtype, device, sparse_pattern
 
     def true_objective(self):
         X = self.X   # row weights, when used, are already folded into X by nmf() (nmf.py:335-338)
         n, d = X.shape
         k = self.W.shape[1]
-        with RRIEngine(n, d, k, dtype=_storage_dtype(X, self._dtype), weighted=self.Wm is not None,
-                       device=self._device) as eng:
-            _upload_problem(eng, X, self.Wm)
+        with _engine_with_problem(X, self.Wm, k, _storage_dtype(X, self._dtype), self._device,
+                                  self._sparse_pattern) as eng:
             eng.set_W(self.W)
             eng.set_T(self.T)
             eng.set_params(reg_w_l1=self.reg_w_l1, reg_w_l2=self.reg_w_l2, reg_t_l1=self.reg_t_l1,
@@ -64,9 +66,72 @@ class TrueObjComputer(object):
         return self.obj
 
 
+SPARSE_PATTERN_MAX_DENSITY = 0.35   # below this share of observed entries the pattern-only residual moves fewer bytes
+
+
+def _observed_csr(X, W_mat):
+    """X on the observation pattern of W_mat as ONE canonical CSR matrix (stored entries = observed entries,
+    explicit zeros kept), or None when that view does not exist: dense inputs, weights other than 0/1, or X with
+    non-zeros outside the pattern (they are invisible to every masked sum, but the reset search of nmf.py:770-773
+    looks at all of X)."""
+    if not (scipy.sparse.issparse(X) and scipy.sparse.issparse(W_mat)):
+        return None
+    M = W_mat.tocsr()
+    if not M.has_canonical_format:
+        M = M.copy()
+        M.sum_duplicates()
+    Xc = X.tocsr()
+    if not Xc.has_canonical_format:
+        Xc = Xc.copy()
+        Xc.sum_duplicates()
+    if Xc.nnz == M.nnz and np.array_equal(Xc.indptr, M.indptr) and np.array_equal(Xc.indices, M.indices):
+        vals = Xc.data
+    else:
+        d = M.shape[1]
+        rows_of = lambda A: np.repeat(np.arange(A.shape[0], dtype=np.int64), np.diff(A.indptr))
+        key_m = rows_of(M) * d + M.indices
+        nz = Xc.data != 0
+        key_x = (rows_of(Xc) * d + Xc.indices)[nz]
+        pos = np.searchsorted(key_m, key_x)
+        pos_ok = pos < key_m.size
+        if not np.all(pos_ok) or not np.array_equal(key_m[pos], key_x):
+            return None
+        vals = np.zeros(M.nnz, dtype=Xc.data.dtype if Xc.data.dtype.kind == 'f' else np.float64)
+        vals[pos] = Xc.data[nz]
+    return scipy.sparse.csr_matrix((vals, M.indices, M.indptr), shape=M.shape)
+
+
+def _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern=None):
+    """Engine with X and the weights on the device.  scipy sparse X / 0-1 sparse W_mat go up as CSR: onto a
+    pattern-only handle (no dense n x d array at all) when X lives on the pattern and the pattern is sparse enough
+    -- `sparse_pattern` True / False forces the choice --, else densified / bit-packed on the device (SURVEY.md 8f
+    rank 3); dense inputs as they are."""
+    n, d = X.shape
+    A = None
+    if W_mat is not None and sparse_pattern is not False:
+        A = _observed_csr(X, W_mat)
+        if A is not None and sparse_pattern is None and A.nnz > SPARSE_PATTERN_MAX_DENSITY * float(n) * d:
+            A = None
+        if A is None and sparse_pattern is True:
+            raise ValueError('sparse_pattern=True needs scipy sparse X and 0/1 W_mat with X zero outside the pattern')
+    if A is not None:
+        eng = RRIEngine(n, d, k, dtype=sdt, weighted='sparse', device=device)
+        try:
+            eng.upload_observed_csr(A)
+        except Exception:
+            eng.close()
+            raise
+        return eng
+    eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device)
+    try:
+        _upload_problem(eng, X, W_mat)
+    except Exception:
+        eng.close()
+        raise
+    return eng
+
+
 def _upload_problem(eng, X, W_mat):
-    """X and the weights to the device.  scipy sparse inputs go up as CSR and are densified / bit-packed there
-    (SURVEY.md 8f rank 3); dense inputs as they are."""
     if scipy.sparse.issparse(X):
         eng.upload_X_csr(X)
     else:
@@ -82,7 +147,7 @@ def _sparse_mask_or_dense(W_mat):
     """a scipy sparse W_mat stays sparse only when it is an observation pattern (all stored values 1)"""
     if W_mat is None or not scipy.sparse.issparse(W_mat):
         return W_mat
-    W_mat = W_mat.tocsr()
+    W_mat = W_mat.tocsr(copy=True)      # the caller's matrix is never modified
     W_mat.eliminate_zeros()
     return W_mat if np.all(W_mat.data == 1) else W_mat.toarray()
 
@@ -154,7 +219,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0,
         diagnostics=[], store_gradients=False,
         ind_rows_to_store=None, eps_gauss_t=None, delta_gauss_t=None,
-        *, dtype=None, device=0, device_init=None):
+        *, dtype=None, device=0, device_init=None, sparse_pattern=None):
     """Non-negative factorisation X ~ W T by rank-one residue iteration; see the module docstring and
     the reference's docstring (nmf.py:109-269) for the parameters.  Returns a dict with 'W', 'T',
     'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
@@ -223,9 +288,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         raise ValueError('W_in has wrong dimensions, must be n*k')
     if not _is_empty(T_in) and np.shape(T_in) != (k, d):
         raise ValueError('T_in has wrong dimensions, must be k*d')
-    eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device)
+    eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern)
     try:
-        _upload_problem(eng, X, W_mat)
         on_device = device_init if device_init is not None else (float(n) * d >= DEVICE_INIT_MIN_ELEMS)
         W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X, k=k, init=init,
                                         random_state=random_state, project_T_each_iter=project_T_each_iter,
@@ -317,7 +381,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if compute_obj_each_iter:
         rtv['obj_history'] = obj_history
         calc = TrueObjComputer(X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, W_mat, w_row,
-                               dtype=dtype, device=device)
+                               dtype=dtype, device=device, sparse_pattern=sparse_pattern)
         calc.obj = obj_history[-1] if obj_history else np.inf
         rtv['obj_calculator'] = calc
     rtv['iter_cputime'] = iter_cputime

@@ -41,9 +41,23 @@ class _FactorPair(object):
 
 
 def _observed_mask(X):
+    """W_mat of the recommender flavour: 1 where X holds a non-zero rating (sklearn_interface.py:99-102)"""
+    if sp.issparse(X):
+        M = X.copy()
+        M.data = np.ones(M.nnz)
+        return M
     M = np.zeros(X.shape)
     M[X.nonzero()] = 1
     return M
+
+
+def _ratings_matrix(values, ij, shape):
+    """the ratings as a CSR matrix: what the reference densifies with .toarray() (sklearn_interface.py:78-97)
+    stays sparse here -- nmf() then keeps X, W_mat and the residual on the observed entries only"""
+    A = sp.coo_matrix((np.asarray(values, dtype=np.float64), (ij[:, 0], ij[:, 1])), shape=shape).tocsr()
+    A.sum_duplicates()
+    A.eliminate_zeros()      # a zero is "not observed" (W_mat = [X != 0])
+    return A
 
 
 class NMF_RS_Estimator(_FactorPair, sklearn.base.BaseEstimator):
@@ -72,22 +86,22 @@ class NMF_RS_Estimator(_FactorPair, sklearn.base.BaseEstimator):
         if self.use_validation_early_stopping:
             ij_tr, ij_val, r_tr, r_val = train_test_split(X, y, test_size=0.05, random_state=0,
                                                           stratify=None)
-            Xtr = sp.coo_matrix((r_tr, (ij_tr[:, 0], ij_tr[:, 1])), shape=shape).toarray()
-            Xv = sp.coo_matrix((r_val, (ij_val[:, 0], ij_val[:, 1])), shape=shape).toarray()
-            vi, vj = Xv.nonzero()
+            Xtr = _ratings_matrix(r_tr, ij_tr, shape)
+            Xv = _ratings_matrix(r_val, ij_val, shape).tocoo()
+            vi, vj, vr = Xv.row, Xv.col, Xv.data
             lo, hi = self.min_rating, self.max_rating
 
             def RMSE_val(X_ignored, W, T):
-                pred = np.clip(np.dot(W, T), lo, hi)
-                return np.sqrt(np.mean((pred[vi, vj] - Xv[vi, vj]) ** 2))
+                pred = np.clip(np.einsum('ij,ji->i', W[vi, :], T[:, vj]), lo, hi)
+                return np.sqrt(np.mean((pred - vr) ** 2))
 
-            # same score without bringing W, T to the host and forming the n x d product there: nmf() evaluates
-            # callbacks that carry `device_entries` with rri_masked_rmse on the device
-            RMSE_val.device_entries = (vi, vj, Xv[vi, vj], lo, hi)
+            # same score without bringing W, T to the host: nmf() evaluates callbacks that carry `device_entries`
+            # with rri_masked_rmse on the device
+            RMSE_val.device_entries = (vi, vj, vr, lo, hi)
             self.early_stop = RMSE_val
         else:
             self.early_stop = False
-            Xtr = sp.coo_matrix((y, (X[:, 0], X[:, 1])), shape=shape).toarray()
+            Xtr = _ratings_matrix(y, X, shape)
         W_in, T_in = self._warm_start()
         soln = _nmf(Xtr, self.k, max_iter=self.max_iter, max_time=7200, compute_obj_each_iter=True,
                     reset_topic_method=None, early_stop=self.early_stop, project_T_each_iter=False,

@@ -190,6 +190,37 @@ def test_device_randomized_svd_follows_sklearn(shape, k):
         assert np.abs(a[0] - b[0]).max() < 1e-8 and np.abs(a[1] - b[1]).max() < 1e-8, init
 
 
+def test_observed_pattern_view_of_sparse_inputs():
+    """nmf()'s choice of the pattern-only handle: X must live on the 0/1 pattern of W_mat; explicit zero ratings
+    stay observed; inputs are never modified"""
+    import scipy.sparse as sp
+    from rri_nmf_amd.nmf import _observed_csr, _sparse_mask_or_dense
+    rs = np.random.RandomState(0)
+    M = (rs.rand(30, 20) < 0.3).astype(float)
+    X = rs.rand(30, 20) * M
+    Ms, Xs = sp.csr_matrix(M), sp.csr_matrix(X)
+    A = _observed_csr(Xs, Ms)                                  # same structure: taken as it is
+    assert A is not None and np.array_equal(A.toarray(), X) and A.nnz == int(M.sum())
+    X2 = X.copy()
+    obs = np.argwhere(M > 0)
+    X2[tuple(obs[3])] = 0.0                                    # an observed zero: X has one stored entry fewer
+    A2 = _observed_csr(sp.csr_matrix(X2), Ms)
+    assert A2 is not None and A2.nnz == Ms.nnz and np.array_equal(A2.toarray(), X2)
+    assert np.array_equal(A2.indices, Ms.indices) and np.array_equal(A2.indptr, Ms.indptr)
+    X3 = X.copy()
+    X3[tuple(np.argwhere(M == 0)[5])] = 1.5                    # a value outside the pattern: no pattern-only view
+    assert _observed_csr(sp.csr_matrix(X3), Ms) is None
+    assert _observed_csr(X, Ms) is None and _observed_csr(Xs, M) is None        # dense inputs
+    coo = sp.coo_matrix(X)                                     # other sparse formats, unsorted
+    assert np.array_equal(_observed_csr(coo, sp.csc_matrix(M)).toarray(), X)
+    W5 = sp.csr_matrix(M * 5.0)
+    keep = W5.data.copy()
+    assert isinstance(_sparse_mask_or_dense(W5), np.ndarray)   # weights other than 0/1: dense path
+    Wz = sp.csr_matrix((np.array([1.0, 0.0, 1.0]), np.array([0, 1, 2]), np.array([0, 3] + [3] * 29)), shape=(30, 20))
+    out = _sparse_mask_or_dense(Wz)
+    assert sp.issparse(out) and out.nnz == 2 and Wz.nnz == 3 and np.array_equal(W5.data, keep)   # inputs untouched
+
+
 def test_initialize_and_validate_matches_oracle():
     from rri_nmf_amd.nmf import _initialize_and_validate
     X = planted_X(50, 40, 4, dtype=np.float64)
@@ -210,9 +241,13 @@ def test_estimator_plumbing_with_oracle_solver(monkeypatch):
     from rri_nmf_amd import sklearn_interface as si
     from rri_nmf_amd.matrixops import proj_mat_to_simplex
 
-    def oracle_nmf(*a, **kw):
+    def oracle_nmf(X, *a, **kw):
         kw.setdefault('objective_always', True)   # the reference as shipped
-        return orc.nmf(*a, **kw)
+        if sp.issparse(X):                         # the RS estimator hands nmf() CSR ratings and a CSR pattern; the
+            X = X.toarray()                        # reference (and so the oracle) takes what .toarray() gives
+        if sp.issparse(kw.get('W_mat')):
+            kw['W_mat'] = kw['W_mat'].toarray()
+        return orc.nmf(X, *a, **kw)
     monkeypatch.setattr(si._nmf_module, 'nmf', oracle_nmf)
     g = load_golden('g1_tm_estimator')
     X = g['X']

@@ -275,9 +275,12 @@ def test_sparse_inputs_are_ingested_as_csr():
     Wm[X.nonzero()] = 1.0
     p = dict(max_iter=5, eps_stop=-1, W_in=g['W0'], T_in=g['T0'], reset_topic_method=None, t_row_sum=1.0)
     a = nmf_mod.nmf(X, 7, W_mat=Wm, **p)
-    b = nmf_mod.nmf(Xs, 7, W_mat=sp.csr_matrix(Wm), **p)
+    b = nmf_mod.nmf(Xs, 7, W_mat=sp.csr_matrix(Wm), sparse_pattern=False, **p)     # densified on the device
     assert np.array_equal(a['W'], b['W']) and np.array_equal(a['T'], b['T'])
     assert np.allclose(a['obj_history'], b['obj_history'], rtol=1e-13)
+    b = nmf_mod.nmf(Xs, 7, W_mat=sp.csr_matrix(Wm), **p)                           # residual kept on the pattern only
+    assert relfro(a['W'], b['W']) < 1e-10 and relfro(a['T'], b['T']) < 1e-10
+    assert np.allclose(a['obj_history'], b['obj_history'], rtol=1e-10)
     # unweighted, float32 storage, ragged shape; and own NNDSVD start from the sparse matrix
     rs = np.random.RandomState(0)
     D = (rs.rand(333, 129) < 0.07) * rs.rand(333, 129)

@@ -102,3 +102,37 @@ def test_explicit_zero_ratings_and_empty_pattern():
         e.set_params(**kw)
         with pytest.raises(AssertionError):
             e.sweep(1)
+
+
+def test_nmf_and_estimator_take_the_pattern_only_path():
+    """nmf() with scipy sparse X and W_mat: pattern-only handle (default below 35 % observed) = densified handle =
+    dense inputs, to rounding; the RS estimator (which now hands nmf() CSR ratings) against the reference's vectors"""
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd import sklearn_interface as si
+    n, d, k = 300, 120, 4
+    X, M, W0, T0 = _problem(n, d, k, 0.15, seed=7)
+    kw = dict(W_in=W0, T_in=T0, max_iter=6, eps_stop=-1, t_row_sum=1.0, reset_topic_method=None,
+              compute_obj_each_iter=True)
+    a = nmf_mod.nmf(sp.csr_matrix(X), k, W_mat=sp.csr_matrix(M), **kw)                          # auto: pattern-only
+    b = nmf_mod.nmf(sp.csr_matrix(X), k, W_mat=sp.csr_matrix(M), sparse_pattern=False, **kw)    # densified on device
+    c = nmf_mod.nmf(X, k, W_mat=M, **kw)                                                        # dense inputs
+    for r in (b, c):
+        assert relfro(a['W'], r['W']) < 1e-10 and relfro(a['T'], r['T']) < 1e-10
+        assert np.allclose(a['obj_history'], r['obj_history'], rtol=1e-10)
+    assert abs(a['obj_calculator'].true_objective() - a['obj_history'][-1]) <= 1e-10 * a['obj_history'][-1]
+    with pytest.raises(ValueError):
+        Xo = X.copy()
+        Xo[M == 0] = 0.3
+        nmf_mod.nmf(sp.csr_matrix(Xo), k, W_mat=sp.csr_matrix(M), sparse_pattern=True, **kw)
+    # initialisation from the sparse ratings (NNDSVD of W_mat .* X through scikit-learn's sparse path)
+    e1 = nmf_mod.nmf(sp.csr_matrix(X), k, W_mat=sp.csr_matrix(M), max_iter=4, eps_stop=-1, t_row_sum=1.0,
+                     reset_topic_method=None, random_state=0)
+    e2 = nmf_mod.nmf(X, k, W_mat=M, max_iter=4, eps_stop=-1, t_row_sum=1.0, reset_topic_method=None, random_state=0)
+    assert relfro(e1['W'], e2['W']) < 1e-6 and relfro(e1['T'], e2['T']) < 1e-6
+    g4 = load_golden('g4_wrri')
+    R = g4['X']
+    E = si.NMF_RS_Estimator(R.shape[0], R.shape[1], 5, random_state=0, max_iter=20).fit_from_Xtr(R)
+    assert abs(E.score(R) - float(g4['rs_es_score'])) < 1e-6
+    E2 = si.NMF_RS_Estimator(R.shape[0], R.shape[1], 5, random_state=0, max_iter=20,
+                             use_validation_early_stopping=False).fit_from_Xtr(sp.csr_matrix(R))
+    assert abs(E2.score(R) - float(g4['rs_noes_score'])) < 1e-6

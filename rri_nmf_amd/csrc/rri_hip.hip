@@ -741,7 +741,8 @@ void enqueue_from(rri_ctx* c, Cursor cur) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;
             for (int t = t0; t < k; ++t) {
                 const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
-                if (!c->resid_valid || (t == 0 && ph == 0)) w_refresh(c);   // once per sweep (and after resets)
+                // once per sweep (and after resets), unless rri_objective has just rebuilt it from the same W, T
+                if (!c->resid_valid || (t == 0 && ph == 0 && !c->resid_fresh)) w_refresh(c);
                 if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, s, t);
                 if (!c->prm.fix_W) enqueue_wW_half(c, s, t);
             }
@@ -1467,7 +1468,18 @@ rri_status rri_objective_parts(rri_ctx* c, double out[3]) {
     if (c->weighted && !c->have_M) return fail(c, RRI_ERR_INVALID, "weighted handle without a mask");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->rowobj) HIPCHK(c, hipMalloc((void**)&c->rowobj, (size_t)c->n * sizeof(double)));
-    DISPATCH(c, L::resid(c, c->weighted != 0, false, c->rowobj, nullptr));
+    if (c->weighted) {
+        // the objective needs M .* (X - W T) -- which is the maintained residual: store it while it is being
+        // computed, and the sweep that follows skips its own rebuild (nmf() asks for the objective after
+        // every sweep, nmf.py:488-490)
+        DISPATCH(c, L::resid(c, true, true, c->rowobj, nullptr));
+        c->resid_valid = true;
+        c->resid_fresh = true;
+        c->dt_pending = false;
+        c->carry_valid = false;
+    } else {
+        DISPATCH(c, L::resid(c, false, false, c->rowobj, nullptr));
+    }
     hipLaunchKernelGGL(k_vec_sum_argmax, dim3(1), dim3(1024), 0, c->stream, (const double*)c->rowobj, c->n,
                        c->dtmp, (i64*)nullptr);
     double base = 0.0;

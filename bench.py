@@ -243,10 +243,10 @@ def main():
     arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else 1.0
     bytes_per_launch = float(n_local) * d * 4 * arrays_per_launch
     if sparse:
-        # per topic step and observed entry: pass B reads (index, value) of the CSR copy = 8 B; pass C reads and
-        # rewrites both copies = 2 x (4 + 4 + 4) B; two timed passes per step -> 16 B per entry and pass on average
-        # (the gathered factor tables, 32 B per row / column, are L2-resident and not counted)
-        bytes_per_launch = 16.0 * nnz
+        # per topic step and observed entry: pass B reads (uint16 offset, fp32 value) of the row copy = 6 B; pass C
+        # reads and rewrites both copies = 2 x (2 + 4 + 4) B; two timed passes per step -> 13 B per entry and pass on
+        # average (the factor tables, staged in LDS once per workgroup, are not counted)
+        bytes_per_launch = 13.0 * nnz
     achieved = bytes_per_launch / (pass_avg_ms * 1e-3) / 1e9 if launches else 0.0
     sweeps_per_s = args.steps / elapsed
     shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
@@ -265,7 +265,7 @@ def main():
                                   % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2))) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                     'kernel': ('k_sp_seg<float,...> passes B (CSR copy: read) and C (CSR + CSC copies: read, write), '
+                     'kernel': ('k_sp_blk<float,...> passes B (row copy: read) and C (row + column copies: read, write), '
                                 'averaged; %d observed entries' % nnz if sparse else
                                 'k_wpass<float,...> passes B (read E, mask) and C (read E, mask; write E), averaged; mask '
                                 + ('bit-packed' if mask_packed else 'fp32') if weighted
@@ -273,11 +273,11 @@ def main():
                      'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},
         'sweep_level': {'global_sweeps_per_s': sweeps_per_s,
                         'timed_launch_samples': launches,
-                        'survey_formula': ('32*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' if sparse
+                        'survey_formula': ('26*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' if sparse
                                            else '4*k*n*d*4 B per sweep (dense fp32 mask, residual not rewritten)' if weighted
                                            else '2*k*n*d*4 B per sweep (two BLAS2 passes per topic step)'),
-                        'algorithmic_GBps_2knd': (32.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9,
-                        'frac_of_8TBps_2knd': (32.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
+                        'algorithmic_GBps_2knd': (26.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9,
+                        'frac_of_8TBps_2knd': (26.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
                         'kernel_avg_ms': {'pass': pass_avg_ms, 'wcol': wcol_ms / max(n1, 1),
                                           'trow_chain_segment': trow_ms / max(n2, 1)}},
     }

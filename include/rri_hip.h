@@ -36,6 +36,8 @@ extern "C" {
 #endif
 
 #define RRI_ABI_VERSION 1
+/* the Gram part of the reduce buffer travels as this many slice sums (see rri_topic_reduce_local) */
+#define RRI_GRAM_SLICES 8
 
 typedef struct rri_ctx rri_ctx; /* opaque */
 
@@ -165,7 +167,8 @@ rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 
 /* ---- row-sharded multi-GPU (one process per GPU; the caller owns the collective) ---- */
 /* A topic step splits at the one cross-row reduction it needs.  rri_topic_reduce_local
- * leaves this rank's partial sums [w_t^T X (d) | w_t^T W (k) | ||w_t||^2 | sum W[:,t-1] | pad]
+ * leaves this rank's partial sums [w_t^T X (LD) | RRI_GRAM_SLICES x (w_t^T W (k), ||w_t||^2, sum W[:,t-1])]
+ * (LD = d rounded up to the 16-byte row stride; a Gram entry is the sum of its slices)
  * in the reduce buffer; the caller all-reduces (sum) that buffer over the ranks (RCCL over
  * xGMI via torch.distributed) and calls rri_topic_finish, which is rank-local.
  * Weighted handles (WRRI, nmf.py:687-701): the buffer is [numerator w_t^T Rt (LD) | denominator
@@ -174,6 +177,11 @@ rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 rri_status rri_reduce_buffer(rri_ctx* ctx, void** dev_ptr, int64_t* n_elems); /* dtype = handle's */
 rri_status rri_bind_reduce_buffer(rri_ctx* ctx, void* dev_ptr, int64_t n_elems);
 rri_status rri_topic_reduce_local(rri_ctx* ctx, int32_t t);
+/* Host access to the first `count` doubles of the reduce buffer between rri_topic_reduce_local and
+ * rri_topic_finish: what a caller needs to perturb the T-row sums -- the Gaussian mechanism of nmf.py:422-435
+ * adds its noise to wR and nw there.  Blocking. */
+rri_status rri_reduce_read(rri_ctx* ctx, double* out, int64_t count);
+rri_status rri_reduce_write(rri_ctx* ctx, const double* in, int64_t count);
 rri_status rri_topic_finish(rri_ctx* ctx, int32_t t);
 /* only the W-column half of topic t (a sharded run resuming after a T-row reset) */
 rri_status rri_topic_finish_w(rri_ctx* ctx, int32_t t);

@@ -337,7 +337,34 @@ def g8():
     save('g8_init', X=X, W_expected=Wt, T_expected=Tt, W_ref_here=W, T_ref_here=T)
 
 
+# ---------------------------------------------------------------- G9
+def g9():
+    """Gaussian mechanism on the T-row sums (nmf.py:422-435), numpy's global RNG seeded before every call.
+    `small` = noise far below the signal (sigma 0.016), `large` = sigma 16: denominators clipped at 0 and the
+    c <= 0 branches of qf_min on most steps."""
+    n, d, k = 240, 90, 4
+    X = planted_X(n, d, k, seed=5, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=6)
+    rs = np.random.RandomState(7)
+    M = (rs.rand(n, d) < 0.4).astype(np.float64)
+    out = dict(shape=np.array([n, d, k]), seed=np.array([11]))
+    for tag, eps_g in (('small', 1e5), ('large', 1e2)):
+        np.random.seed(11)
+        soln = rnmf(X, k, W_in=copy_in(W0), T_in=copy_in(T0), max_iter=3, eps_stop=-1, t_row_sum=1.0,
+                    eps_gauss_t=eps_g, delta_gauss_t=0.1)
+        out['plain_%s_W' % tag], out['plain_%s_T' % tag] = soln['W'], soln['T']
+        np.random.seed(11)
+        soln = rnmf(M * X, k, W_in=copy_in(W0), T_in=copy_in(T0), W_mat=M, max_iter=3, eps_stop=-1, t_row_sum=1.0,
+                    reset_topic_method=None, eps_gauss_t=eps_g, delta_gauss_t=0.1)
+        out['weighted_%s_W' % tag], out['weighted_%s_T' % tag] = soln['W'], soln['T']
+    np.random.seed(11)
+    soln = rnmf(X, k, W_in=copy_in(W0), T_in=copy_in(T0), max_iter=3, eps_stop=-1, t_row_sum=1.0,
+                project_T_each_iter=True, w_row_sum=1.0, eps_gauss_t=1e5, delta_gauss_t=0.1)
+    out['tm_small_W'], out['tm_small_T'] = soln['W'], soln['T']
+    save('g9_gaussian_mechanism', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     for g in which:
-        {'g1': g1_g2, 'g3': g3, 'g4': g4, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8}[g]()
+        {'g1': g1_g2, 'g3': g3, 'g4': g4, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}[g]()

@@ -366,8 +366,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False, random_state=Non
         do_final_project_W=True, project_T_each_iter=False, t_row_sum=None,
         early_stop=None, reset_topic_method='max_resid_document', fix_reset_seed=False,
         n_resets=23, reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0, diagnostics=[],
-        objective_always=False, on_sweep=None):
-    """Restatement of nmf.py:98-560 (store_gradients / Gaussian mechanism omitted).
+        objective_always=False, on_sweep=None, eps_gauss_t=None, delta_gauss_t=None):
+    """Restatement of nmf.py:98-560 (store_gradients omitted: the reference cannot return from such a call).
 
     `objective_always=True` reproduces the reference AS SHIPPED, whose module
     logger has level NOTSET so `logger.level <= logging.DEBUG` (nmf.py:366) forces
@@ -438,6 +438,15 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False, random_state=Non
         for t in range(k):  # nmf.py:415-476
             if not fix_T:
                 wR, nw = residual_products_T(X, W, T, t, W_mat)
+                if eps_gauss_t and delta_gauss_t:   # nmf.py:422-435: Gaussian mechanism on the T-row sums
+                    from scipy.stats import norm as gaussian
+                    c2 = 2 * np.log(1.25 / float(delta_gauss_t)) + 0.001
+                    df2 = 1000.0
+                    sigma2 = c2 * df2 ** 2 * (1 / float(eps_gauss_t)) ** 2
+                    N = gaussian(0, np.sqrt(sigma2))
+                    wR = wR + N.rvs(np.size(wR)).reshape(np.shape(wR))
+                    nw = nw + N.rvs(np.size(nw)).reshape(np.shape(nw))
+                    nw = np.maximum(nw, 0)
                 numer = wR - reg_t_l1
                 denom = nw + reg_t_l2
                 s = t_row_sum if project_T_each_iter else None

@@ -10,6 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RRI_HIP_LIB', os.path.join(_PKG, 'lib', 'librri_hip.so'))
 
+RRI_GRAM_SLICES = 8     # include/rri_hip.h
 RRI_OK, RRI_PAUSED = 0, 1
 RRI_ERR_INVALID, RRI_ERR_HIP, RRI_ERR_UNSUPPORTED = -1, -2, -3
 RRI_ERR_UNBOUNDED, RRI_ERR_W_COL_ZERO, RRI_ERR_NOT_IMPLEMENTED = -4, -5, -6
@@ -72,6 +73,8 @@ PROTOTYPES = {
     'rri_Xt_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
     'rri_reduce_buffer': (_I32, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     'rri_bind_reduce_buffer': (_I32, [_P, _P, _I64]),
+    'rri_reduce_read': (_I32, [_P, C.POINTER(C.c_double), _I64]),
+    'rri_reduce_write': (_I32, [_P, C.POINTER(C.c_double), _I64]),
     'rri_topic_reduce_local': (_I32, [_P, _I32]),
     'rri_topic_finish': (_I32, [_P, _I32]),
     'rri_topic_finish_w': (_I32, [_P, _I32]),

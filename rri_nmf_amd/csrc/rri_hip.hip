@@ -1673,6 +1673,24 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
     return RRI_OK;
 }
 
+rri_status rri_reduce_read(rri_ctx* c, double* out, int64_t count) {
+    CHECK_CTX(c);
+    if (!out || count < 0 || count > c->red_elems) return fail(c, RRI_ERR_INVALID, "bad reduce-buffer range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->red, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
+rri_status rri_reduce_write(rri_ctx* c, const double* in, int64_t count) {
+    CHECK_CTX(c);
+    if (!in || count < 0 || count > c->red_elems) return fail(c, RRI_ERR_INVALID, "bad reduce-buffer range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->red, in, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
 rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));

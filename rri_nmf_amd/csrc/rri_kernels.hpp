@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "rri_device.hpp"
+#include "rri_hip.h"
 
 namespace rri {
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
 // [k+1] = sum_i W[i,t] (new).  T T[t]^T arrives as nsplit partial vectors from k_tgram.
 // =========================================================================================
 constexpr int WCOL_TILES = 1;   // 64-row tiles per k_wcol block (1 = most blocks in flight)
-constexpr int GRAM_SLICES = 8;  // k_reduce sums the Gpart rows in this many slices; consumers add the slices
+constexpr int GRAM_SLICES = RRI_GRAM_SLICES;  // k_reduce sums the Gpart rows in this many slices; consumers add the slices
 
 template <bool UPDATE, bool CARRY>
 __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, int n, int k, int t, int tn,

@@ -327,6 +327,60 @@ class RRIEngine(object):
     def topic_finish(self, t):
         self._check(self._lib.rri_topic_finish(self._h, int(t)))
 
+    def reduce_read(self, count):
+        out = np.empty(int(count), dtype=np.float64)
+        self._check(self._lib.rri_reduce_read(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), int(count)))
+        return out
+
+    def reduce_write(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._lib.rri_reduce_write(self._h, v.ctypes.data_as(C.POINTER(C.c_double)), int(v.size)))
+
+    def _stepping_event(self):
+        """polls; a reset event is resolved as rri_sweep's are.  Returns its (kind, topic) or None."""
+        if self.poll() != _capi.RRI_PAUSED:
+            return None
+        kind, topic, _ = self.pending_event()
+        self._resolve_event()
+        return kind, topic
+
+    def sweep_with_T_noise(self, draw):
+        """One sweep in which every T-row step sees wR + noise and max(nw + noise, 0): the Gaussian mechanism of
+        nmf.py:422-435.  `draw(m)` returns m samples; it is called in the reference's order (wR first, then nw,
+        after any reset of the previous column has drawn its own numbers).  The sums of a topic step are taken on
+        the device, perturbed in the reduce buffer on the host, and the step finishes on the device: the split
+        stepping of the row-sharded path with the host in the place of the all-reduce."""
+        d, k = self.d, self.k
+        ld = -(-d // (16 // self.dtype.itemsize)) * (16 // self.dtype.itemsize)
+        for t in range(k):
+            self.topic_reduce_local(t)
+            self.topic_finish(-1)                       # the column check of topic t-1 (nmf.py:471-476)
+            if self._stepping_event() is not None:      # dead column: reset, then the sums again
+                self.topic_reduce_local(t)
+            if self.weighted:                           # red = [a | nw]; wR = a + t .* nw (rri_wrri_kernels.hpp)
+                r = self.reduce_read(2 * ld)
+                trow = self.get_T()[t, :]
+                a, nw = r[:d], r[ld:ld + d]
+                wR = a + trow * nw + draw(d)
+                nw2 = np.maximum(nw + draw(d), 0)
+                r[:d] = wR - trow * nw2
+                r[ld:ld + d] = nw2
+            else:                                       # red = [w^T X | slices of (w^T W, ||w||^2, .)]
+                r = self.reduce_read(ld + _capi.RRI_GRAM_SLICES * (k + 2))
+                r[:d] += draw(d)                        # wR = w^T X - (w^T W) T: the noise passes through
+                at = [ld + g * (k + 2) + k for g in range(_capi.RRI_GRAM_SLICES)]
+                nw = float(sum(r[i] for i in at)) + float(np.asarray(draw(1)).ravel()[0])
+                for i in at:
+                    r[i] = 0.0
+                r[at[0]] = max(nw, 0.0)
+            self.reduce_write(r)
+            self.topic_finish(t)
+            if self._stepping_event() is not None:      # the new T row was (numerically) zero: reset, then its W half
+                self.topic_finish_w(t)
+        self.topic_reduce_local(0)                      # the last column's check rides on topic 0's sums
+        self.topic_finish(-1)
+        self._stepping_event()
+
     def topic_finish_w(self, t):
         self._check(self._lib.rri_topic_finish_w(self._h, int(t)))
 

@@ -225,11 +225,21 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
     is tracked, 'obj_history' and 'obj_calculator'; 'diagnostics' when callbacks are given."""
     if store_gradients or ind_rows_to_store is not None:
+        # the reference cannot return from such a call: nmf.py:543 hands stack_matrices its reshape lambda as
+        # `dict_key`, which indexes an ndarray with it (IndexError) -- there is no behaviour to reproduce
         raise NotImplementedError('store_gradients is not available on the device path '
                                   '(SURVEY.md section 8f rank 4)')
-    if eps_gauss_t or delta_gauss_t:
-        raise NotImplementedError('the Gaussian mechanism (eps_gauss_t/delta_gauss_t) is not available '
-                                  'on the device path (SURVEY.md section 8f rank 4)')
+    draw_noise = None
+    if eps_gauss_t and delta_gauss_t and not fix_T:
+        # Gaussian mechanism on the T-row sums (nmf.py:422-435; Dwork & Roth p. 261)
+        if fix_W or k < 2:
+            raise NotImplementedError('the Gaussian mechanism needs both halves free and k >= 2 on the device path')
+        from scipy.stats import norm as gaussian
+        c2 = 2 * np.log(1.25 / float(delta_gauss_t)) + 0.001
+        df2 = 1000.0
+        sigma2 = c2 * df2 ** 2 * (1 / float(eps_gauss_t)) ** 2
+        noise = gaussian(0, np.sqrt(sigma2))            # draws from numpy's global RNG, as the reference's does
+        draw_noise = lambda m: np.asarray(noise.rvs(m), dtype=np.float64).ravel()
     # scipy sparse X / 0-1 sparse W_mat are ingested as CSR (no host densification); row weights need a dense X
     if scipy.sparse.issparse(X):
         X = X.tocsr() if w_row is None else X.toarray()
@@ -337,7 +347,10 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
                 eng.snapshot()
 
             sweep_t0 = time.time()
-            eng.sweep(1)                          # the topic loop, nmf.py:415-476
+            if draw_noise is None:
+                eng.sweep(1)                      # the topic loop, nmf.py:415-476
+            else:
+                eng.sweep_with_T_noise(draw_noise)
 
             if project_W_each_iter and not fix_W and w_row_sum is not None:   # nmf.py:481-484
                 eng.project_W_rows(w_row_sum if np.isscalar(w_row_sum) else w_row_sum.ravel())

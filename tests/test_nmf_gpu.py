@@ -339,3 +339,20 @@ def test_device_products_and_device_init(shape, store):
     # scikit-learn factorises a float32 X in float32 arithmetic; the device products are float64 either way
     tol = 1e-6 if store == np.float64 else 1e-3
     assert relfro(a['W'], b['W']) < tol and relfro(a['T'], b['T']) < tol
+
+
+def test_gaussian_mechanism_against_the_reference():
+    """eps_gauss_t / delta_gauss_t (nmf.py:422-435): the T-row sums leave the device, get the reference's noise
+    (same scipy call on numpy's global RNG, same order) and the step finishes on the device"""
+    from test_oracle_golden import _g9_cases
+    nmf_mod, _ = api()
+    g, k, W0, T0, cases = _g9_cases()
+    for name, X, M, kw in cases:
+        np.random.seed(int(g['seed'][0]))
+        r = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, W_mat=M, **kw)
+        assert relfro(r['W'], g[name + '_W']) < 1e-8 and relfro(r['T'], g[name + '_T']) < 1e-8, \
+            (name, relfro(r['W'], g[name + '_W']), relfro(r['T'], g[name + '_T']))
+    with pytest.raises(NotImplementedError):
+        nmf_mod.nmf(cases[0][1], k, W_in=W0, T_in=T0, fix_W=True, max_iter=1, eps_gauss_t=1.0, delta_gauss_t=0.1)
+    with pytest.raises(NotImplementedError):
+        nmf_mod.nmf(cases[0][1], k, W_in=W0, T_in=T0, max_iter=1, store_gradients=True)

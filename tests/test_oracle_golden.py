@@ -235,3 +235,27 @@ def test_rare_branches():
                 project_W_each_iter=True, compute_obj_each_iter=True)
     assert same(np.array(r['obj_history']), g['stop_obj']) and same(r['W'], g['stop_W'])
     assert len(r['obj_history']) < 40
+
+
+def _g9_cases():
+    g = load_golden('g9_gaussian_mechanism')
+    n, d, k = [int(v) for v in g['shape']]
+    X = planted_X(n, d, k, seed=5, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=6)
+    M = (np.random.RandomState(7).rand(n, d) < 0.4).astype(np.float64)
+    base = dict(max_iter=3, eps_stop=-1, t_row_sum=1.0, delta_gauss_t=0.1)
+    cases = []
+    for tag, eps_g in (('small', 1e5), ('large', 1e2)):
+        cases.append(('plain_' + tag, X, None, dict(base, eps_gauss_t=eps_g)))
+        cases.append(('weighted_' + tag, M * X, M, dict(base, eps_gauss_t=eps_g, reset_topic_method=None)))
+    cases.append(('tm_small', X, None, dict(base, eps_gauss_t=1e5, project_T_each_iter=True, w_row_sum=1.0)))
+    return g, k, W0, T0, cases
+
+
+def test_gaussian_mechanism():
+    """nmf.py:422-435 with numpy's global RNG seeded as the capture was"""
+    g, k, W0, T0, cases = _g9_cases()
+    for name, X, M, kw in cases:
+        np.random.seed(int(g['seed'][0]))
+        r = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), W_mat=M, **kw)
+        assert same(r['W'], g[name + '_W']) and same(r['T'], g[name + '_T']), name

@@ -223,7 +223,8 @@ template <bool UPDATE, bool CARRY>
 __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, int n, int k, int t, int tn,
                                               const double* __restrict__ Ypart, int npanels,
                                               const double* __restrict__ Ttpart, int nsplit,
-                                              double* __restrict__ Gpart, int sweep, KParams p, DevState* st) {
+                                              double* __restrict__ Gpart, double* __restrict__ xyp, int sweep,
+                                              KParams p, DevState* st) {
     // Block = TILES tiles of 64 rows of W (lane = row); its 4 waves split the k columns (wave w takes
     // l = w, w+4, ...): four times the waves of a row-per-thread layout, dependent chains a quarter as
     // long.  Gram partials of the tiles add up in LDS (one owner wave per column: fixed order).
@@ -310,6 +311,10 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
             const double nwp = wave_sum<double>(wn * wn);
             const double swp = wave_sum<double>(wnew);
             if (lane == 0) { gsh[k] += nwp; gsh[k + 1] += swp; }
+            if (UPDATE) {   // <w_t, X t_t> of this block's rows: the cross term of the objective, for free
+                const double xy = wave_sum<double>(wnew * y);
+                if (lane == 0) xyp[(i64)blockIdx.x * TILES + tile] = xy;
+            }
         } else if (wave == 1 && UPDATE && CARRY) {
             const double gt = wave_sum<double>(wn * wnew);   // Gram entry against the NEW column t
             if (lane == 0) gsh[t] += gt;
@@ -818,6 +823,41 @@ __global__ __launch_bounds__(256) void k_norms(const double* __restrict__ A, i64
     s2 = block_sum(s2, scratch);
     s3 = block_sum(s3, scratch);
     if (threadIdx.x == 0) { out[blockIdx.x * 3 + 0] = s1; out[blockIdx.x * 3 + 1] = s2; out[blockIdx.x * 3 + 2] = s3; }
+}
+
+// sum of squares of the stored X (float64 accumulation): out[b] partial of block b
+template <typename SX>
+__global__ __launch_bounds__(256) void k_sqsum(const SX* __restrict__ X, i64 ldx, i64 n, i64 d, double* __restrict__ out) {
+    __shared__ double scratch[40];
+    double s = 0.0;
+    const i64 total = n * d;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 r = idx / d, c = idx - r * d;
+        const double v = (double)X[r * ldx + c];
+        s = fma(v, v, s);
+    }
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// Gram matrix of the rows of a k x len matrix: G[a*k + b] = <A[a,:], A[b,:]>, one workgroup per (a, b >= a)
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, i64 ld, i64 len, int k, double* __restrict__ G) {
+    __shared__ double scratch[40];
+    const int a = blockIdx.x, b = blockIdx.y;
+    if (b < a) return;
+    double s = 0.0;
+    for (i64 i = threadIdx.x; i < len; i += 256) s = fma(A[(i64)a * ld + i], A[(i64)b * ld + i], s);
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) { G[a * k + b] = s; G[b * k + a] = s; }
+}
+
+// out[t] = sum_b part[t * nb + b], fixed order, one workgroup per t
+__global__ __launch_bounds__(256) void k_rows_sum(const double* __restrict__ part, int nb, double* __restrict__ out) {
+    __shared__ double scratch[40];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += part[(i64)blockIdx.x * nb + b];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 // sum of a double vector -> out[0]; argmax (first index) -> out_idx[0].  One workgroup.

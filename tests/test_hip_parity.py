@@ -348,3 +348,36 @@ def test_weighted_recsys_fixture(dtype):
                 objs.append(e.objective())
         assert np.all(np.diff(objs) <= 1e-9 * abs(objs[0]))
         assert np.allclose(objs, g['c%d_obj' % ci], rtol=(1e-6 if dtype == np.float64 else 1e-4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('store', [np.float32, np.float64])
+def test_objective_without_a_pass_over_X(store, monkeypatch):
+    """after a complete sweep rri_objective assembles 1/2||X - WT||^2 from ||X||^2, the cross terms the W halves
+    left behind and the two Gram matrices; it must agree with the residual-based value (and with numpy) and fall back
+    to the residual whenever something changed W or T from outside"""
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = 2111, 517, 7
+    X = planted_X(n, d, k, seed=0, dtype=store)
+    X64 = X.astype(np.float64)
+    W0, T0 = scaled_init(X64, k, seed=1)
+    direct = lambda W, T: 0.5 * float(((X64 - W @ T) ** 2).sum())
+    for flags in (dict(), dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0), dict(fix_T=True),
+                  dict(reg_w_l1=0.01, reg_t_l2=0.1)):
+        with RRIEngine(n, d, k, dtype=store) as e:
+            e.upload_X(X), e.set_W(W0), e.set_T(T0)
+            e.set_params(**flags)
+            o0 = e.objective_parts()[0]                      # nothing has run: residual path
+            assert abs(o0 - direct(W0, T0)) <= 1e-12 * o0
+            for sweeps in (1, 2):
+                e.sweep(sweeps)
+                fast = e.objective_parts()[0]
+                W, T = e.get_W(), e.get_T()
+                want = direct(W, T)
+                assert abs(fast - want) <= 1e-11 * max(want, 1e-3 * float((X64 ** 2).sum())), (flags, fast, want)
+            e.set_W(W)                                       # same values, but set from outside: back to the residual
+            slow = e.objective_parts()[0]
+            assert abs(slow - want) <= 1e-12 * want and abs(slow - fast) <= 1e-10 * want
+            e.update_T_row(1)                                # a lone half step: the cross terms are stale
+            W, T = e.get_W(), e.get_T()
+            assert abs(e.objective_parts()[0] - direct(W, T)) <= 1e-12 * direct(W, T)

@@ -217,6 +217,7 @@ struct TimedScope {
 // ---- typed launch helpers ------------------------------------------------------------------
 // geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
 int g_pass_unroll = 8, g_pass_nt = 1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8)
+int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
@@ -225,38 +226,39 @@ struct LaunchX {
     typedef SX Elem;
     static size_t pass_shmem(const rri_ctx* c) { return (6 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
     template <bool DO_Y, bool DO_Z, bool UPD, int U, bool NT, bool RS>
-    static void pass_k(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b) {
+    static void pass_k(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b,
+                       const TgramJob& job) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
         typedef typename std::conditional<UPD, SX, const SX>::type XT;
-        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb), dim3(256),
+        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
                            pass_shmem(c), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
-                           c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st);
+                           c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st, job);
     }
     template <bool DO_Y, bool DO_Z, bool UPD>
     static void pass_cfg(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a,
-                         const double* b) {
+                         const double* b, const TgramJob& job = TgramJob{}) {
         if (g_pass_unroll == 8 && g_pass_rs && DO_Y) {
-            if (g_pass_nt) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, trow, wc, a, b);
-            else pass_k<DO_Y, DO_Z, UPD, 8, false, true>(c, Xp, trow, wc, a, b);
+            if (g_pass_nt) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, trow, wc, a, b, job);
+            else pass_k<DO_Y, DO_Z, UPD, 8, false, true>(c, Xp, trow, wc, a, b, job);
             return;
         }
         const int key = g_pass_unroll * 2 + (g_pass_nt ? 1 : 0);
         switch (key) {
-#define RRI_CASE(U_)                                                                            \
-    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false, false>(c, Xp, trow, wc, a, b); break;   \
-    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true, false>(c, Xp, trow, wc, a, b); break;
+#define RRI_CASE(U_)                                                                                 \
+    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false, false>(c, Xp, trow, wc, a, b, job); break;   \
+    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true, false>(c, Xp, trow, wc, a, b, job); break;
             RRI_CASE(4)
             RRI_CASE(8)
             RRI_CASE(16)
 #undef RRI_CASE
-            default: pass_k<DO_Y, DO_Z, UPD, 8, true, false>(c, Xp, trow, wc, a, b);
+            default: pass_k<DO_Y, DO_Z, UPD, 8, true, false>(c, Xp, trow, wc, a, b, job);
         }
     }
-    // row dots against T[t,:] (DO_Y) and column sums against W[:,tz] (DO_Z)
+    // row dots against T[t,:] (DO_Y) and column sums against W[:,tz] (DO_Z); `job`: the Gram row of T[t,:] rides along
     template <bool DO_Y, bool DO_Z>
-    static void pass(rri_ctx* c, int t, int tz) {
+    static void pass(rri_ctx* c, int t, int tz, const TgramJob& job = TgramJob{}) {
         TimedScope ts(c, 0);
-        pass_cfg<DO_Y, DO_Z, false>(c, c->X, c->T + (i64)t * c->LD, c->W + (i64)tz * c->ldw, nullptr, nullptr);
+        pass_cfg<DO_Y, DO_Z, false>(c, c->X, c->T + (i64)t * c->LD, c->W + (i64)tz * c->ldw, nullptr, nullptr, job);
     }
     // R <- R - a b^T fused with the row dots (against trow) and column sums (against wc) of the new R
     static void rank1(rri_ctx* c, void* R, const double* a, const double* b, const double* trow, const double* wc) {
@@ -628,15 +630,20 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int k = c->k;
     const bool carry_next = (k > 1) && !c->prm.fix_T;
     const int tn = (t + 1) % k;
-    {
+    // T T[t,:]^T for k_wcol; the T-row checks ride along only when a T half of this topic just ran and left its sums.
+    // Where a pass follows, the job joins its grid (no launch of its own); with T fixed there is no pass.
+    const int finish = (LK::light(c) && !c->prm.fix_T && !c->skip_row_finish) ? 1 : 0;
+    c->skip_row_finish = false;
+    TgramJob job{};
+    if (c->prm.fix_T || g_side_jobs == 0) {
         TimedScope ts(c, 2);
-        // the T-row checks ride on k_tgram only when a T half of this topic just ran and left its sums
-        const int finish = (LK::light(c) && !c->prm.fix_T && !c->skip_row_finish) ? 1 : 0;
-        c->skip_row_finish = false;
         LK::tgram(c, t, finish, sweep);
+    } else {
+        job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->ntb,
+                       c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
     }
     if (carry_next) {
-        DISPATCH(c, (L::template pass<true, true>(c, t, tn)));
+        DISPATCH(c, (L::template pass<true, true>(c, t, tn, job)));
         LK::wcol<true, true>(c, t, tn, sweep);
         c->carry_valid = true;
         c->carry_topic = tn;
@@ -651,7 +658,7 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
             }
             LK::wcol_src<true, false>(c, t, tn, sweep, c->Qt + (i64)t * c->ldw, 1);
         } else {
-            DISPATCH(c, (L::template pass<true, false>(c, t, tn)));
+            DISPATCH(c, (L::template pass<true, false>(c, t, tn, job)));
             LK::wcol<true, false>(c, t, tn, sweep);
         }
         // position of the NEXT step, where a resumed run continues
@@ -862,6 +869,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
+    if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
 #define CR(call)                                                                                   \

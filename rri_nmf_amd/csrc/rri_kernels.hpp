@@ -102,6 +102,41 @@ __device__ __forceinline__ void stream_store(V* p, const V& v) {
     else *p = v;
 }
 
+// A small job that rides in the grid of a streaming pass instead of costing a launch of its own: the Gram row
+// T T[t,:]^T of the topic whose row dots the pass takes (k_tgram below describes it).  T[t,:] is final when the
+// pass starts and the result is first read by the k_wcol after the pass, so the two have no order to keep.
+// The first `nblocks` workgroups of the grid do the job, the others the pass.
+struct TgramJob {
+    const double* T; i64 ldt; int d, k, t;
+    double* Ttpart; const double* tpart; int ntb, nsplit, finish, sweep;
+    KParams p; DevState* st;
+    int nblocks;          // k * nsplit, or 0: no job
+};
+__device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ldt, int d, int k, int t, int l, int split,
+                                            int ns, double* __restrict__ Ttpart, const double* __restrict__ tpart,
+                                            int nblk, int finish, int sweep, const KParams& p, DevState* st,
+                                            double* scratch) {
+    const int chunk = (d + ns - 1) / ns;
+    const int j0 = split * chunk, j1 = min(d, j0 + chunk);
+    double acc = 0.0;
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) acc = fma(T[(i64)l * ldt + j], T[(i64)t * ldt + j], acc);
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) Ttpart[split * k + l] = acc;
+    if (finish && l == 0 && split == 0) {
+        double ps = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) ps += tpart[b];
+        ps = block_sum(ps, scratch);
+        if (threadIdx.x == 0) {
+            const int mode = st->tmode;
+            st->nt1 = (mode == 0) ? ps : 1.0;
+            st->sumT = ps;
+            if (!(ps > 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0) {
+                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+            }
+        }
+    }
+}
+
 // Block = 4 waves = 4 ADJACENT column panels (one per wave, 64 lanes * 16 B each) x one row block.
 // Every wave walks all rows of the block, U rows in flight; the 4 row-dot partials of a row meet in
 // LDS slots [wave][row] and are added in a fixed order at the end (Ypart has one slice per 4 panels);
@@ -112,12 +147,20 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
                                               const double* __restrict__ trow, const double* __restrict__ wcol,
                                               double* __restrict__ Ypart, double* __restrict__ Zpart, i64 ldz,
                                               int rpb, int npg, const double* __restrict__ avec,
-                                              const double* __restrict__ bvec, const DevState* __restrict__ st) {
+                                              const double* __restrict__ bvec, const DevState* __restrict__ st,
+                                              const TgramJob job) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
     constexpr int PW = 64 * VN;          // columns per wave
     if (st->halt) return;
+    if ((int)blockIdx.x < job.nblocks) {
+        __shared__ double jscratch[40];
+        tgram_block(job.T, job.ldt, job.d, job.k, job.t, (int)blockIdx.x % job.k, (int)blockIdx.x / job.k, job.nsplit,
+                    job.Ttpart, job.tpart, job.ntb, job.finish, job.sweep, job.p, job.st, jscratch);
+        return;
+    }
+    const int bid = (int)blockIdx.x - job.nblocks;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ysh = reinterpret_cast<double*>(smem);            // [4 waves][rpb]
     double* wsh = ysh + 4 * rpb;                              // [rpb]
@@ -126,8 +169,8 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* tile = ash + rpb + wave * (8 * 72);               // [4][8*72] private row-sum tiles (RS)
-    const int pg = blockIdx.x % npg;
-    const int rb = blockIdx.x / npg;
+    const int pg = bid % npg;
+    const int rb = bid / npg;
     const int row0 = rb * rpb;
     const int row1 = min(n, row0 + rpb);
     const int col = (pg * 4 + wave) * PW + lane * VN;
@@ -576,27 +619,7 @@ __global__ __launch_bounds__(256) void k_tgram(const double* __restrict__ T, i64
                                                int nblk, int finish, int sweep, KParams p, DevState* st) {
     if (st->halt) return;
     __shared__ double scratch[40];
-    const int l = blockIdx.x;
-    const int ns = gridDim.y;
-    const int chunk = (d + ns - 1) / ns;
-    const int j0 = blockIdx.y * chunk, j1 = min(d, j0 + chunk);
-    double acc = 0.0;
-    for (int j = j0 + threadIdx.x; j < j1; j += 256) acc = fma(T[(i64)l * ldt + j], T[(i64)t * ldt + j], acc);
-    acc = block_sum(acc, scratch);
-    if (threadIdx.x == 0) Ttpart[blockIdx.y * k + l] = acc;
-    if (finish && blockIdx.x == 0 && blockIdx.y == 0) {
-        double ps = 0.0;
-        for (int b = threadIdx.x; b < nblk; b += 256) ps += tpart[b];
-        ps = block_sum(ps, scratch);
-        if (threadIdx.x == 0) {
-            const int mode = st->tmode;
-            st->nt1 = (mode == 0) ? ps : 1.0;
-            st->sumT = ps;
-            if (!(ps > 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0) {
-                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
-            }
-        }
-    }
+    tgram_block(T, ldt, d, k, t, blockIdx.x, blockIdx.y, gridDim.y, Ttpart, tpart, nblk, finish, sweep, p, st, scratch);
 }
 
 // W[:,t] *= nt1 (nmf.py:450-452); only observable when fix_W keeps the column.

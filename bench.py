@@ -282,15 +282,26 @@ def main():
                                           'trow_chain_segment': trow_ms / max(n2, 1)}},
     }
 
-    pmc_file = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic_%s.json' % args.config)
-    if os.path.exists(pmc_file) and not weighted:
+    # HBM bytes of the dominant kernel(s) from PMC counters collected by the same command under rocprofv3 --pmc
+    # (separate FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py).  gfx950: FETCH_SIZE counts half the bytes of
+    # a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section), hence 2 x FETCH + WRITE.
+    pmc_file = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic_%s.json' % args.config)
+    if os.path.exists(pmc_file):
         try:
             pm = json.load(open(pmc_file))
-            key = [kk for kk in pm if 'k_pass<float, true, true, false' in kk][0]
-            # gfx950: FETCH_SIZE counts half the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM)
-            out['roofline']['traffic'] = (2.0 * pm[key]['FETCH_SIZE_KB_avg'] + pm[key]['WRITE_SIZE_KB_avg']) * 1024.0
+            if sparse:      # one timed pass = pass B, or pass C on both copies
+                keys = [kk for kk in pm if 'k_sp_blk<float' in kk]
+                per_launch = 0.5
+            elif weighted:  # passes B and C (the prologue variant runs 3 times per call: left out)
+                keys = [kk for kk in pm if 'k_wpass<float' in kk and pm[kk]['launches'] > 10]
+                per_launch = 0.5
+            else:
+                keys = [kk for kk in pm if 'k_pass<float, true, true, false' in kk]
+                per_launch = 1.0
+            tot = sum(2.0 * pm[kk]['FETCH_SIZE_KB_avg'] + pm[kk]['WRITE_SIZE_KB_avg'] for kk in keys) * 1024.0
+            out['roofline']['traffic'] = tot * per_launch
             out['roofline']['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same '
-                                                 'kernel and shape, profiles/%s; FETCH_SIZE doubled per the gfx950 '
+                                                 'kernels and shape, profiles/%s; FETCH_SIZE doubled per the gfx950 '
                                                  'correction' % os.path.basename(pmc_file))
         except Exception:  # noqa: BLE001
             pass

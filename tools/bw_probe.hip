@@ -118,6 +118,44 @@ __global__ __launch_bounds__(256) void cp_stride(const float4* __restrict__ s, f
     for (; i < nvec; i += stride) d[i] = s[i];
 }
 
+// in-place read-modify-write (the access pattern of the rank-one residual update), grid-stride
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void rmw_stride(float4* __restrict__ d, i64 nvec, float c) {
+    const i64 stride = (i64)gridDim.x * 256;
+    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < nvec; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(d + i + u * stride) : d[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = v[u] - c; if (NT) __builtin_nontemporal_store(v[u], d + i + u * stride); else d[i + u * stride] = v[u]; }
+    }
+    for (; i < nvec; i += stride) d[i] = d[i] - c;
+}
+// in-place, the pass pattern: block = 4 waves = 4 adjacent 1 KiB panels x a row block, U rows in flight per wave
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void rmw_panel(float* __restrict__ X, i64 ldx, int n, int rpb, int npg, float c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const int row0 = rb * rpb, row1 = min(n, row0 + rpb);
+    const i64 col = (i64)(pg * 4 + wave) * 256 + lane * 4;
+    if (col >= ldx) return;
+    for (int r = row0; r < row1; r += U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4* xp = (float4*)(X + (i64)(r + u) * ldx + col);
+            v[u] = (r + u < row1) ? (NT ? __builtin_nontemporal_load(xp) : *xp) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4* xp = (float4*)(X + (i64)(r + u) * ldx + col);
+            v[u] = v[u] - c;
+            if (r + u < row1) { if (NT) __builtin_nontemporal_store(v[u], xp); else *xp = v[u]; }
+        }
+    }
+}
+
 template <typename F>
 double timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -173,6 +211,25 @@ int main(int argc, char** argv) {
         char nm[96];
         snprintf(nm, 96, "cp_stride U4 grid %d (r+w bytes)", g); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((cp_stride<4, false>), dim3(g), dim3(256), 0, 0, (const float4*)X, (float4*)Y, nvec));
         snprintf(nm, 96, "cp_stride U4 NT grid %d (r+w bytes)", g); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((cp_stride<4, true>), dim3(g), dim3(256), 0, 0, (const float4*)X, (float4*)Y, nvec));
+    }
+    for (int g : {2048, 8192, 32768}) {
+        char nm[96];
+        snprintf(nm, 96, "rmw_stride U4 grid %d (r+w bytes)", g); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_stride<4, false>), dim3(g), dim3(256), 0, 0, (float4*)Y, nvec, 1.0f));
+        snprintf(nm, 96, "rmw_stride U4 NT grid %d (r+w bytes)", g); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_stride<4, true>), dim3(g), dim3(256), 0, 0, (float4*)Y, nvec, 1.0f));
+        snprintf(nm, 96, "rmw_stride U8 NT grid %d (r+w bytes)", g); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_stride<8, true>), dim3(g), dim3(256), 0, 0, (float4*)Y, nvec, 1.0f));
+        snprintf(nm, 96, "cp_stride U8 NT grid %d (r+w bytes)", g); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((cp_stride<8, true>), dim3(g), dim3(256), 0, 0, (const float4*)X, (float4*)Y, nvec));
+    }
+    {
+        const int npg = (d + 1023) / 1024;
+        for (int wgs : {2048, 8192}) {
+            int nrb = wgs / npg; if (nrb < 1) nrb = 1;
+            int rpb = (n + nrb - 1) / nrb; nrb = (n + rpb - 1) / rpb;
+            char nm[96];
+            snprintf(nm, 96, "rmw_panel U8 NT wgs~%d (rpb %d)", wgs, rpb); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<8, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
+            snprintf(nm, 96, "rmw_panel U8 wgs~%d", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<8, false>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
+            snprintf(nm, 96, "rmw_panel U4 NT wgs~%d", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<4, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
+            snprintf(nm, 96, "rmw_panel U16 NT wgs~%d", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<16, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
+        }
     }
     return 0;
 }

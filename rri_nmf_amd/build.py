@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, 'csrc', 'rri_hip.hip')
-DEPS = [SRC] + [os.path.join(PKG, 'csrc', f) for f in ('rri_kernels.hpp', 'rri_device.hpp')] + \
+DEPS = [SRC] + sorted(os.path.join(PKG, 'csrc', f) for f in os.listdir(os.path.join(PKG, 'csrc')) if f.endswith('.hpp')) + \
     [os.path.join(ROOT, 'include', 'rri_hip.h')]
 LIB = os.path.join(PKG, 'lib', 'librri_hip.so')
 

@@ -1,7 +1,7 @@
 """nmf(): drop-in for the reference's solver entry point (/root/reference/src/rri_nmf/nmf.py:98-560)
 with the sweep / topic loop running on an MI355X through librri_hip.so.
 
-Same signature, defaults, return keys and error behaviour as the reference; two keyword-only
+Same signature, defaults, return keys and error behaviour as the reference; keyword-only
 additions select the device side:
     dtype   storage type of X (and the mask) in HBM: float32 or float64.  None = float32 when X is
             float32, else float64.  The arithmetic is float64 either way (see csrc/rri_kernels.hpp).

@@ -47,8 +47,8 @@ __device__ __forceinline__ double group_sum(double v) {
 //   WRITE: val[p] = e' (rounded to the storage type; the sums then use the stored value, as the dense pass does)
 //   DO_S : S1[blk][s] = sum e' * V[g] ,  S2[blk][s] = sum V[g]^2
 // Every segment is padded to a multiple of 4 entries (pad offset SP_PAD), so a lane moves 4 consecutive entries
-// per load: 8 bytes of offsets + 16 (fp32) / 32 (fp64) bytes of values, 4 such quads in flight per lane -- about
-// 6 KB of reads in flight per wave; with one entry per load the passes ran at a third of the bandwidth, bound by
+// per load: 8 bytes of offsets + 16 (fp32) / 32 (fp64) bytes of values, 8 such quads in flight per lane -- about
+// 12 KB of reads in flight per wave; with one entry per load the passes ran at a third of the bandwidth, bound by
 // the round trips of too few bytes in flight.  One segment per group of LPS lanes; 1024 threads share the tables.
 constexpr unsigned short SP_PAD = 0xFFFF;
 template <typename SX> struct SpQuad;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work
         if (DO_S) tv[g] = in ? (TF)V[g0 + g] : TF(0);
     }
     __syncthreads();
-    constexpr int UNR = 4;
+    constexpr int UNR = 8;
     constexpr int GROUPS = 1024 / LPS;
     const int sub = threadIdx.x % LPS, grp = threadIdx.x / LPS;
     const i64* sp = segptr + (i64)w.blk * (nseg + 1);

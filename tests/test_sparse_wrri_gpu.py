@@ -136,3 +136,20 @@ def test_nmf_and_estimator_take_the_pattern_only_path():
     E2 = si.NMF_RS_Estimator(R.shape[0], R.shape[1], 5, random_state=0, max_iter=20,
                              use_validation_early_stopping=False).fit_from_Xtr(sp.csr_matrix(R))
     assert abs(E2.score(R) - float(g4['rs_noes_score'])) < 1e-6
+
+
+@pytest.mark.parametrize('n,d,store', [(12000, 150, np.float64), (300, 11000, np.float64), (23000, 120, np.float32),
+                                       (200, 21000, np.float32)])
+def test_more_than_one_block_per_copy(n, d, store):
+    """shapes wider than an LDS block (10240 fp32 / 5120 fp64 factors): the row copy is cut into column blocks
+    (several Ypart panels), the column copy into row blocks (several Zpart rows)"""
+    k = 4
+    X, M, W0, T0 = _problem(n, d, k, 0.05, seed=11, store=store)
+    flags = dict(t_row_sum=1.0, reset_topic_method=None)
+    Wd, Td, od, _ = _run(X, M, W0, T0, k, 3, False, store, flags)
+    Ws, Ts, os_, _ = _run(X, M, W0, T0, k, 3, True, store, flags)
+    # fp32: with ~6 observations per row the W update is poorly determined, and the two schedules round the stored
+    # residual (and, pattern-only, the LDS factor tables) differently: same objective, W to 1e-3
+    tol = 1e-10 if store == np.float64 else 1e-3
+    assert relfro(Ws, Wd) < tol and relfro(Ts, Td) < tol, (relfro(Ws, Wd), relfro(Ts, Td))
+    assert abs(os_ - od) <= (1e-10 if store == np.float64 else 1e-5) * abs(od)

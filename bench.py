@@ -58,6 +58,8 @@ def parse():
     ap.add_argument('--cpu-sweeps', type=int, default=2)
     ap.add_argument('--cpu-rows', type=int, default=10000, help='rows of X in the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--storage', default='f32', choices=['f32', 'f64'],
+                    help='storage type of X / mask / residual in HBM (the BASELINE configs are fp32; arithmetic is float64 either way)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the row-sharded driver (RCCL all-reduce per topic step) even with one rank')
     return ap.parse_args()
@@ -173,7 +175,9 @@ def main():
         X.mul_(Mask)
         torch.cuda.synchronize()
     sparse = bool(cfg.get('sparse'))
-    eng, red, stream = make_device_shard(n_local, d, k, dtype=np.float32, device_index=local_rank,
+    sdt = np.float32 if args.storage == 'f32' else np.float64
+    es = 4 if args.storage == 'f32' else 8
+    eng, red, stream = make_device_shard(n_local, d, k, dtype=sdt, device_index=local_rank,
                                          weighted='sparse' if sparse else weighted)
     nnz = 0
     if sparse:
@@ -193,6 +197,11 @@ def main():
         del X, Mask, A
         torch.cuda.empty_cache()
     else:
+        if args.storage == 'f64':
+            X = X.double()
+            if weighted:
+                Mask = Mask.double()
+            torch.cuda.synchronize()   # the handle's stream does not wait for torch's: the tensors must be complete
         eng.bind_X_device(X.data_ptr(), X.stride(0))
         if weighted:
             eng.bind_mask_device(Mask.data_ptr(), Mask.stride(0))
@@ -241,12 +250,12 @@ def main():
     # topic step: the roofline line is priced on what is moved, never on the larger formula
     mask_packed = weighted and os.environ.get('RRI_MASK_BITS', '1') != '0'
     arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else 1.0
-    bytes_per_launch = float(n_local) * d * 4 * arrays_per_launch
+    bytes_per_launch = float(n_local) * d * es * arrays_per_launch
     if sparse:
         # per topic step and observed entry: pass B reads (uint16 offset, fp32 value) of the row copy = 6 B; pass C
         # reads and rewrites both copies = 2 x (2 + 4 + 4) B; two timed passes per step -> 13 B per entry and pass on
         # average (the factor tables, staged in LDS once per workgroup, are not counted)
-        bytes_per_launch = 13.0 * nnz
+        bytes_per_launch = (6.0 + 5.0 * es) / 2.0 * nnz   # fp32: 13 B
     achieved = bytes_per_launch / (pass_avg_ms * 1e-3) / 1e9 if launches else 0.0
     sweeps_per_s = args.steps / elapsed
     shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
@@ -260,7 +269,7 @@ def main():
         'config': {'workload': cfg['name'] + (' per GPU (row shard), %d x %d global' % (n_global, d)
                                               if world > 1 and cfg['scaling'] == 'weak' else ''),
                    'n_global': n_global, 'n_per_gpu': n_local, 'd': d, 'k': k,
-                   'x_storage': 'fp32 on the observed pattern (%d entries, CSR + CSC), upload %.2f s' % (nnz, t_up) if sparse else 'fp32 in HBM', 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
+                   'x_storage': '%s on the observed pattern (%d entries, CSR + CSC), upload %.2f s' % (args.storage, nnz, t_up) if sparse else '%s in HBM' % args.storage, 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
                    'parallelism': 'row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step'
                                   % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2))) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -276,8 +285,8 @@ def main():
                         'survey_formula': ('26*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' if sparse
                                            else '4*k*n*d*4 B per sweep (dense fp32 mask, residual not rewritten)' if weighted
                                            else '2*k*n*d*4 B per sweep (two BLAS2 passes per topic step)'),
-                        'algorithmic_GBps_2knd': (26.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9,
-                        'frac_of_8TBps_2knd': (26.0 * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * 4) * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
+                        'algorithmic_GBps_2knd': ((6.0 + 5.0 * es) * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es) * sweeps_per_s / 1e9,
+                        'frac_of_8TBps_2knd': ((6.0 + 5.0 * es) * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es) * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
                         'kernel_avg_ms': {'pass': pass_avg_ms, 'wcol': wcol_ms / max(n1, 1),
                                           'trow_chain_segment': trow_ms / max(n2, 1)}},
     }

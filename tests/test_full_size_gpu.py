@@ -155,6 +155,7 @@ def test_weighted_dense_and_pattern_only_paths_agree_at_full_size(problem):
     M64 = Mask.double()
     X64 = X.double() * M64
     del Mask
+    torch.cuda.synchronize()     # bound device memory must be complete: the handle's stream does not wait for torch's
     res = {'dense64': run(lambda: RRIEngine(N, D, K, dtype=np.float64, weighted=True),
                           lambda e: (e.bind_X_device(X64.data_ptr(), X64.stride(0)),
                                      e.bind_mask_device(M64.data_ptr(), M64.stride(0))))}

@@ -99,9 +99,9 @@ const char* rri_last_error(const rri_ctx* ctx);   /* NULL ctx: error of the last
 rri_status rri_upload_X(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype);
 rri_status rri_upload_mask(rri_ctx* ctx, const void* host, int64_t ld, int32_t host_dtype); /* W_mat */
 /* Zero-copy alternative: X (and mask) already in device memory in the handle's dtype,
- * row-major with row stride ld (a multiple of 16 bytes, base 16-byte aligned).  The memory must be complete when
- * the call is made (synchronise the stream that produced it): the handle's stream does not wait for other streams,
- * and rri_bind_mask_device reads the mask at once to bit-pack it. */
+ * row-major with row stride ld (a multiple of 16 bytes, base 16-byte aligned).  The calls synchronise the device
+ * once, so memory just produced on another stream is complete (rri_bind_mask_device reads the mask at once to
+ * bit-pack it); later changes to the memory are the caller's to order against the handle's stream. */
 rri_status rri_bind_X_device(rri_ctx* ctx, const void* dev, int64_t ld);
 rri_status rri_bind_mask_device(rri_ctx* ctx, const void* dev, int64_t ld);
 /* Ingestion without host densification (the reference densifies with .toarray(), sklearn_interface.py:78-102):

@@ -1260,6 +1260,8 @@ rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
         return fail(c, RRI_ERR_INVALID, "device X must be 16-byte aligned with a 16-byte-multiple row stride >= d");
     if (c->d % c->VN) return fail(c, RRI_ERR_INVALID, "binding device X needs d %% %d == 0 (no pad columns)", c->VN);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());   // the memory may have been produced on another stream a moment ago
     if (c->X && c->own_X) (void)hipFree(c->X);
     c->X = const_cast<void*>(dev);
     c->own_X = false;
@@ -1278,6 +1280,8 @@ rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
         return fail(c, RRI_ERR_INVALID, "device mask must be 16-byte aligned with a 16-byte-multiple row stride >= d");
     if (c->d % c->VN) return fail(c, RRI_ERR_INVALID, "binding a device mask needs d %% %d == 0", c->VN);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());   // the mask is read at once (bit-packing): it must be complete
     if (c->M && c->own_M) (void)hipFree(c->M);
     c->M = const_cast<void*>(dev);
     c->own_M = false;

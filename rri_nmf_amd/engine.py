@@ -145,8 +145,8 @@ class RRIEngine(object):
         self._check(self._lib.rri_upload_observed_csr(self._h, *args))
 
     def bind_X_device(self, ptr, ld):
-        """X already on the device (row stride ld elements).  The producer's stream must have finished: the handle's
-        stream does not wait for it (torch: torch.cuda.synchronize() or an event wait before binding)."""
+        """X already on the device (row stride ld elements); the call synchronises the device once, later writes
+        to that memory are the caller's to order against the handle's stream"""
         self._check(self._lib.rri_bind_X_device(self._h, C.c_void_p(ptr), int(ld)))
 
     def bind_mask_device(self, ptr, ld):

@@ -182,8 +182,6 @@ def main():
     nnz = 0
     if sparse:
         import scipy.sparse as sp
-        if sharded:
-            raise SystemExit('the sparse-pattern workload is single-GPU')
         nz = Mask.nonzero()                                   # row-major order = CSR order
         counts = torch.bincount(nz[:, 0], minlength=n_local)
         indptr = np.concatenate([[0], np.cumsum(counts.cpu().numpy())]).astype(np.int64)

@@ -1715,7 +1715,6 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
     if (r != RRI_OK) return r;
     if (c->prm.fix_W || c->prm.fix_T || c->k < 2)
         return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping needs k >= 2 and both halves free");
-    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping is not available for sparse-pattern handles");
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->weighted) {

@@ -45,9 +45,15 @@ def _worker(rank, world, port, n, d, k, sweeps, weighted, store, flags, out_dir)
         X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
         lo, hi = shard_rows(n, world, rank)
         eng, red, stream = make_device_shard(hi - lo, d, k, dtype=np.dtype(store), device_index=0, weighted=weighted)
-        eng.upload_X(np.ascontiguousarray(X[lo:hi]))
-        if weighted:
-            eng.upload_mask(np.ascontiguousarray(M[lo:hi]))
+        if weighted == 'sparse':
+            import scipy.sparse as sp
+            A = sp.csr_matrix(M[lo:hi])
+            A.data = np.asarray(X[lo:hi][M[lo:hi] > 0], dtype=np.dtype(store))
+            eng.upload_observed_csr(A)
+        else:
+            eng.upload_X(np.ascontiguousarray(X[lo:hi]))
+            if weighted:
+                eng.upload_mask(np.ascontiguousarray(M[lo:hi]))
         eng.set_W(W0[lo:hi])
         eng.set_T(T0)
         eng.set_params(**flags)
@@ -69,6 +75,8 @@ CASES = {
     'weighted_f32': (1201, 515, 5, 3, True, 'float32', dict(t_row_sum=1.0, reset_topic_method=None)),
     'weighted_f64_regs': (700, 260, 4, 3, True, 'float64', dict(t_row_sum=1.0, reset_topic_method=None, reg_w_l1=0.01,
                                                                reg_t_l1=0.02)),
+    'pattern_only_f64': (1201, 515, 5, 3, 'sparse', 'float64', dict(t_row_sum=1.0, reset_topic_method=None)),
+    'pattern_only_f32_resets_T': (600, 200, 4, 2, 'sparse', 'float32', dict(t_row_sum=1.0, reg_t_l1=1e6)),
     'resets_W': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6)),
     'weighted_resets_T': (600, 200, 4, 2, True, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
 }
@@ -84,7 +92,7 @@ def test_two_shards_on_one_gpu_match_one_engine(name, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), n, d, k, sweeps, weighted, store, flags, str(tmp_path)),
              nprocs=world, join=True)
     X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
-    with RRIEngine(n, d, k, dtype=np.dtype(store), weighted=weighted) as e:
+    with RRIEngine(n, d, k, dtype=np.dtype(store), weighted=bool(weighted)) as e:     # all rows, dense arrays
         e.upload_X(X)
         if weighted:
             e.upload_mask(M)
@@ -95,10 +103,11 @@ def test_two_shards_on_one_gpu_match_one_engine(name, tmp_path):
     parts = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
     W = np.vstack([p['W'] for p in parts])
     assert np.array_equal(parts[0]['T'], parts[1]['T'])              # replicated, bit for bit
-    assert relfro(W, Wa) < 1e-10 and relfro(parts[0]['T'], Ta) < 1e-10, (relfro(W, Wa), relfro(parts[0]['T'], Ta))
+    tol = 1e-10 if store == 'float64' or not weighted else 1e-4    # fp32 residual: the schedules round it differently
+    assert relfro(W, Wa) < tol and relfro(parts[0]['T'], Ta) < tol, (relfro(W, Wa), relfro(parts[0]['T'], Ta))
     assert int(parts[0]['resets']) == int(parts[1]['resets']) == na
     if 'resets' in name:
         assert na >= k
     # the regularisation terms are the caller's to add (ShardedRRI.objective's arguments); compare the data term
     if not any(flags.get(r) for r in ('reg_w_l1', 'reg_t_l1')):
-        assert abs(float(parts[0]['obj']) - obja) <= 1e-10 * abs(obja)
+        assert abs(float(parts[0]['obj']) - obja) <= tol * abs(obja)

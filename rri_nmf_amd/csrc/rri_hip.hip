@@ -218,6 +218,8 @@ struct TimedScope {
 // geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
 int g_pass_unroll = 8, g_pass_nt = 1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8)
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
+int g_resid_waves = 4;  // RRI_RESID_WAVES=8: 128-row instead of 64-row workgroups in k_resid_mfma (measured: no faster)
+int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
@@ -382,6 +384,38 @@ struct LaunchX {
     static void resid(rri_ctx* c, bool masked, bool write_e, double* rowobj, double* rowpos) {
         if (c->sparse) { sp_resid(c, write_e, rowobj, rowpos); return; }   // outside the pattern nothing contributes
         const unsigned nb = (unsigned)((c->n + 63) / 64);
+        if (c->k <= 64 && g_resid_mfma) {   // the k-panel product on the matrix cores
+            const int ks = c->k <= 16 ? 4 : c->k <= 32 ? 8 : c->k <= 48 ? 12 : c->k <= 52 ? 13 : 16;
+            const size_t shm = 2 * (size_t)(4 * ks) * 64 * sizeof(double);
+#define RRI_RESID_M(MK, WE, KS_)                                                                                     \
+    do {                                                                                                             \
+        if (g_resid_waves == 8)                                                                                      \
+            hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 8>), dim3((unsigned)((c->n + 127) / 128)), dim3(512), shm, \
+                               c->stream, (const SX*)c->X, c->ldx, (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, \
+                               c->ldb, (const double*)c->W, c->ldw, (const double*)c->T, c->LD, (int)c->n, (int)c->d,  \
+                               c->k, rowobj, rowpos, (SX*)c->E, c->LD);                                              \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, \
+                               c->ldx, (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, \
+                               c->ldw, (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos,        \
+                               (SX*)c->E, c->LD);                                                                    \
+    } while (0)
+#define RRI_RESID_K(MK, WE)                          \
+    switch (ks) {                                    \
+        case 4: RRI_RESID_M(MK, WE, 4); break;       \
+        case 8: RRI_RESID_M(MK, WE, 8); break;       \
+        case 12: RRI_RESID_M(MK, WE, 12); break;     \
+        case 13: RRI_RESID_M(MK, WE, 13); break;     \
+        default: RRI_RESID_M(MK, WE, 16); break;     \
+    }
+            if (masked && write_e) RRI_RESID_K(true, true)
+            else if (masked) RRI_RESID_K(true, false)
+            else if (write_e) RRI_RESID_K(false, true)
+            else RRI_RESID_K(false, false)
+#undef RRI_RESID_K
+#undef RRI_RESID_M
+            return;
+        }
         const size_t sh = resid_shmem(c);
 #define RRI_RESID(MK, WE)                                                                                       \
     hipLaunchKernelGGL((k_resid<SX, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const SX*)c->X, c->ldx,      \
@@ -869,6 +903,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
+    if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
+    if (const char* e = getenv("RRI_RESID_WAVES")) g_resid_waves = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);

@@ -777,6 +777,159 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
 }
 
 // =========================================================================================
+// k_resid_mfma: the same residual on the matrix cores, for k <= 64: E tile (64 rows x 64 columns per step) =
+// X - W T with v_mfma_f64_16x16x4_f64.  Wave w of the block owns rows 16w .. 16w+15: its A fragments (W rows,
+// one double per lane and k-step: lane l holds W[row l&15][4s + (l>>4)]) stay in registers for the whole row
+// block; the T tile of a step (4 KS x 64 doubles) is shared by the 4 waves through LDS, double-buffered: the loads
+// of step j+1 (T tile and X) are in flight while the 4 KS MFMAs of step j run.
+// The 4 MFMA tiles of a step take INTERLEAVED columns -- tile c owns columns c0 + 4m + c, m < 16 -- so the 4 results
+// a lane holds for one row (f64 MFMA result layout: lane l, register r = row (l>>4) + 4r, tile column l&15) are 4
+// CONSECUTIVE columns of X: one 16-byte load (and store) per lane and row, 256 contiguous bytes per 16 lanes, and
+// one mask nibble.  The T tile is parked in LDS permuted to match (column 4m + c at slot 16c + m), so a B fragment
+// read is 16 consecutive doubles: no bank conflicts.
+// =========================================================================================
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename SX, bool MASKED, bool WRITE_E, int KS, int WAVES>   // KS = k-steps of 4 (4, 8, 12, 13 or 16): k <= 4 KS
+__global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M,
+                                                    i64 ldm, const unsigned* __restrict__ Mb, i64 ldb,
+                                                    const double* __restrict__ Wt, i64 ldw,
+                                                    const double* __restrict__ T, i64 ldt, int n, int d, int k,
+                                                    double* __restrict__ rowobj, double* __restrict__ rowpos,
+                                                    SX* __restrict__ E, i64 lde) {
+    constexpr int kp = 4 * KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tsh = reinterpret_cast<double*>(smem);   // [2][kp][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 row0 = (i64)blockIdx.x * (16 * WAVES) + wave * 16;
+    const int lr = lane & 15, lk = lane >> 4;
+    double afrag[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int l = 4 * s + lk;
+        afrag[s] = (l < k && row0 + lr < n) ? Wt[(i64)l * ldw + row0 + lr] : 0.0;
+    }
+    // cooperative load of a T tile: thread -> column tid & 63 (parked at its permuted slot), rows (tid >> 6) + WAVES i
+    const int tc = tid & 63, tr = tid >> 6;
+    const int slot = 16 * (tc & 3) + (tc >> 2);
+    constexpr int NST = (kp + WAVES - 1) / WAVES;
+    double stage[NST];
+    typedef typename std::conditional<sizeof(SX) == 4, float, double>::type XR;
+    XR xq[4][4];                                     // the lane's 4 rows x 4 consecutive columns of X, as stored
+    auto fetch = [&](i64 c0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int l = tr + WAVES * i;
+            stage[i] = (l < k && c0 + tc < d) ? T[(i64)l * ldt + c0 + tc] : 0.0;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (tr + WAVES * i < kp) tsh[((size_t)buf * kp + tr + WAVES * i) * 64 + slot] = stage[i];
+    };
+    // X: rows row0 + lk + 4r, columns c0 + 4 lr .. + 3 (a 16-byte vector when the storage type is fp32 and the
+    // columns are all there; elementwise at the ragged edge and for fp64 storage)
+    auto fetch_x = [&](i64 c0) {
+        const i64 j = c0 + 4 * lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const i64 i = row0 + lk + 4 * r;
+            bool done = false;
+            if constexpr (sizeof(SX) == 4) {
+                if (i < n && j + 3 < d) {
+                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + i * ldx + j));
+                    xq[r][0] = v[0]; xq[r][1] = v[1]; xq[r][2] = v[2]; xq[r][3] = v[3];
+                    done = true;
+                }
+            }
+            if (!done) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xq[r][c] = (i < n && j + c < d) ? (XR)X[i * ldx + j + c] : XR(0);
+            }
+        }
+    };
+    double so[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
+    fetch(0);
+    fetch_x(0);
+    park(0);
+    __syncthreads();
+    int buf = 0;
+    for (i64 c0 = 0; c0 < d; c0 += 64, buf ^= 1) {
+        const bool more = c0 + 64 < d;
+        if (more) fetch(c0 + 64);                    // the next T tile: in flight during the MFMAs below
+        f64x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const double* tb = tsh + (size_t)buf * kp * 64;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double b = tb[(4 * s + lk) * 64 + 16 * c + lr];
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], b, acc[c], 0, 0, 0);
+            }
+        }
+        // epilogue: e = x - (W T), masked; sums per row; tile c, register r -> row lk + 4r, column 4 lr + c
+        const i64 j0 = c0 + 4 * lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const i64 i = row0 + lk + 4 * r;
+            if (i >= n) continue;
+            unsigned bits = 0xFu;
+            if (MASKED && Mb) bits = Mb[(i >> 3) * ldb + (j0 >> 2)] >> ((int)(i & 7) << 2);
+            double ev[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const i64 j = j0 + c;
+                double e = 0.0, m = 0.0;
+                if (j < d) {
+                    e = (double)xq[r][c] - acc[c][r];
+                    m = !MASKED ? 1.0 : (Mb ? (double)((bits >> c) & 1u) : (double)M[i * ldm + j]);
+                    so[r] += m * e * e;
+                    const double ep = e > 0.0 ? e : 0.0;
+                    sp[r] += ep * ep;
+                }
+                ev[c] = m * e;
+            }
+            if (WRITE_E) {
+                bool stored = false;
+                if constexpr (sizeof(SX) == 4) {
+                    if (j0 + 3 < d) {
+                        const f32x4 o = f32x4{(float)ev[0], (float)ev[1], (float)ev[2], (float)ev[3]};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(E + i * lde + j0));
+                        stored = true;
+                    }
+                }
+                if (!stored) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (j0 + c < d) E[i * lde + j0 + c] = (SX)ev[c];
+                }
+            }
+        }
+        if (more) {
+            fetch_x(c0 + 64);                        // the next X tile: in flight during the next step's MFMAs
+            park(buf ^ 1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            so[r] += __shfl_xor(so[r], off, 64);
+            sp[r] += __shfl_xor(sp[r], off, 64);
+        }
+        const i64 i = row0 + lk + 4 * r;
+        if (lr == 0 && i < n) {
+            if (rowobj) rowobj[i] = so[r];
+            if (rowpos) rowpos[i] = sp[r];
+        }
+    }
+}
+
+// =========================================================================================
 // k_xtt: Qt = (X T^T)^T, k x n k-major: the row products X T[l,:]^T of ALL topics in one pass over X.
 // Used when T is fixed (fold-in / transform, nmf.py:417 `fix_T`): X T^T does not change between
 // sweeps, so every later W-column update reads its X t_t from Qt instead of streaming X again.

@@ -131,6 +131,11 @@ def main():
         sys.exit(relaunch_under_torchrun(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Rehearsal of the multi-rank path on a ONE-GPU box (never the measured configuration): RRI_BENCH_REHEARSAL=1 puts
+    # every rank on device 0 and runs the collectives over gloo (RCCL wants one device per rank)
+    rehearsal = os.environ.get('RRI_BENCH_REHEARSAL', '0') == '1'
+    if rehearsal:
+        local_rank = 0
 
     import numpy as np
     import torch
@@ -145,7 +150,10 @@ def main():
     if sharded:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
     if cfg['scaling'] == 'weak':
         n_local, n_global = cfg['n'], cfg['n'] * world
     else:

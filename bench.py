@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 
 CONFIGS = {
     'c2': dict(n=10000, d=1000, k=20, scaling='weak', name='synthetic dense fp32 X 10000x1000 k=20'),
+    'mid': dict(n=20000, d=5000, k=20, scaling='weak', name='synthetic dense fp32 X 20000x5000 k=20 (not a BASELINE config: a mid-size point)'),
     'c3': dict(n=100000, d=10000, k=50, scaling='weak', name='synthetic dense fp32 X 100000x10000 k=50'),
     'c4': dict(n=1000000, d=10000, k=50, scaling='strong', name='synthetic dense fp32 X 1000000x10000 k=50'),
     'c5': dict(n=100000, d=10000, k=50, scaling='weak', weighted=True,

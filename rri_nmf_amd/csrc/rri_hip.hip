@@ -46,6 +46,17 @@ struct Cursor {
     int sweep, topic, phase;  // phase 0 = T-row half, 1 = W-column half
 };
 
+// host-side flags that describe the state BETWEEN two sweeps (captured sweeps, below)
+struct SteadyState {
+    bool carry_valid, pending_wcheck, resid_valid, resid_fresh, dt_pending, q_valid, skip_row_finish, xy_valid;
+    int carry_topic, pending_wcheck_topic, xy_run;
+    bool operator==(const SteadyState& o) const {
+        return carry_valid == o.carry_valid && pending_wcheck == o.pending_wcheck && resid_valid == o.resid_valid &&
+               resid_fresh == o.resid_fresh && dt_pending == o.dt_pending && q_valid == o.q_valid &&
+               skip_row_finish == o.skip_row_finish && carry_topic == o.carry_topic &&
+               (!pending_wcheck || pending_wcheck_topic == o.pending_wcheck_topic);
+    }
+};
 struct TimedLaunch {
     hipEvent_t a, b;
 };
@@ -106,6 +117,13 @@ struct rri_ctx {
 
     rri_params prm{};
     bool have_params = false, have_X = false, have_W = false, have_T = false, have_M = false;
+
+    // one steady-state sweep captured into a hipGraph (launch-bound sizes): valid while nothing that shapes the
+    // sequence of launches changes (parameters, bound buffers); graph_entry / graph_exit: the host flags it needs
+    // at its start and leaves at its end
+    hipGraphExec_t graph_exec = nullptr;
+    SteadyState graph_entry{}, graph_exit{};
+    long graph_replays = 0;
 
     bool carry_valid = false;
     int carry_topic = -1;
@@ -220,6 +238,8 @@ int g_pass_unroll = 8, g_pass_nt = 1, g_pass_rs = 1;   // RS: LDS row sums (need
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_resid_waves = 4;  // RRI_RESID_WAVES=8: 128-row instead of 64-row workgroups in k_resid_mfma (measured: no faster)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
+int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
+                        // launch-bound sizes, 2 always
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
@@ -630,6 +650,14 @@ void invalidate(rri_ctx* c) {
     c->xy_valid = false;
 }
 
+// the captured sweep bakes in the parameters and every buffer address: whatever changes those drops it
+void drop_graph(rri_ctx* c) {
+    if (c->graph_exec) {
+        (void)hipGraphExecDestroy(c->graph_exec);
+        c->graph_exec = nullptr;
+    }
+}
+
 // ---- the topic-step scheduler ------------------------------------------------------------------
 // carry := Zpart/Gpart hold the partial sums of topic `carry_topic`.
 void enqueue_prologue(rri_ctx* c, int t, int sweep) {
@@ -791,33 +819,64 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     c->carry_topic = tn;
 }
 
-void enqueue_from(rri_ctx* c, Cursor cur) {
+// sweeps [cur .. s_end) of the current call; `sweep_arg_offset` is subtracted from the sweep index the kernels are
+// given (a captured sweep is enqueued as sweep 0: DevState.sweep_base carries the rest)
+void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) {
     const int k = c->k;
     if (c->weighted) {
-        for (int s = cur.sweep; s < c->run_total; ++s) {
+        for (int s = cur.sweep; s < s_end; ++s) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;
+            const int sa = s - sweep_arg_offset;
             for (int t = t0; t < k; ++t) {
                 const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
                 // once per sweep (and after resets), unless rri_objective has just rebuilt it from the same W, T
                 if (!c->resid_valid || (t == 0 && ph == 0 && !c->resid_fresh)) w_refresh(c);
-                if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, s, t);
-                if (!c->prm.fix_W) enqueue_wW_half(c, s, t);
+                if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, sa, t);
+                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t);
             }
         }
         return;
     }
-    for (int s = cur.sweep; s < c->run_total; ++s) {
+    for (int s = cur.sweep; s < s_end; ++s) {
         const int t0 = (s == cur.sweep) ? cur.topic : 0;
+        const int sa = s - sweep_arg_offset;
         for (int t = t0; t < k; ++t) {
             const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
-            if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, s, t, c->prm.fix_W != 0);
-            if (!c->prm.fix_W) enqueue_W_half(c, s, t);
+            if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, sa, t, c->prm.fix_W != 0);
+            if (!c->prm.fix_W) enqueue_W_half(c, sa, t);
         }
     }
+}
+
+void enqueue_final_check(rri_ctx* c, int sweep_arg) {
     if (c->pending_wcheck) {  // last column of the call: report it in this call
-        LK::check_wcol(c, c->pending_wcheck_topic, c->run_total, 0);
+        LK::check_wcol(c, c->pending_wcheck_topic, sweep_arg, 0);
         c->pending_wcheck = false;
     }
+}
+
+void enqueue_from(rri_ctx* c, Cursor cur) {
+    enqueue_range(c, cur, c->run_total);
+    enqueue_final_check(c, c->run_total);
+}
+
+// ---- captured sweeps (hipGraph) ------------------------------------------------------------------------------
+// A sweep of a small problem is a few hundred launches of a few microseconds each: launch-bound.  In the steady
+// state (the sweep before left its carry for topic 0, nothing changed from outside) every sweep enqueues the same
+// launches with the same arguments, so ONE sweep is captured into a hipGraph and replayed.  The host-side flags
+// that describe the state between sweeps are compared before a replay and restored after it.
+// Measured on ROCm 7.2 / MI355X (tools/graph_probe.py, profiles/r01_graph_probe.txt): +1 % (10000 x 1000, k = 20) to
+// +7 % (2000 x 500, k = 10) for back-to-back sweeps, -10 % for nmf()'s sweep + objective loop: the gaps between
+// dependent kernels are on the GPU side, the eager launches already run ahead of it.  Off unless RRI_GRAPH is set.
+SteadyState steady_of(const rri_ctx* c) {
+    return SteadyState{c->carry_valid, c->pending_wcheck, c->resid_valid, c->resid_fresh, c->dt_pending, c->q_valid,
+                       c->skip_row_finish, c->xy_valid, c->carry_topic, c->pending_wcheck_topic, c->xy_run};
+}
+void restore_steady(rri_ctx* c, const SteadyState& s) {
+    c->carry_valid = s.carry_valid; c->pending_wcheck = s.pending_wcheck; c->resid_valid = s.resid_valid;
+    c->resid_fresh = s.resid_fresh; c->dt_pending = s.dt_pending; c->q_valid = s.q_valid;
+    c->skip_row_finish = s.skip_row_finish; c->xy_valid = s.xy_valid; c->carry_topic = s.carry_topic;
+    c->pending_wcheck_topic = s.pending_wcheck_topic; c->xy_run = s.xy_run;
 }
 
 rri_status read_state(rri_ctx* c, DevState* out) {
@@ -860,7 +919,7 @@ rri_status status_from_halt(rri_ctx* c, const DevState& s, int32_t* sweeps_done)
 }
 
 rri_status clear_halt(rri_ctx* c) {
-    HIPCHK(c, hipMemsetAsync(c->st, 0, 16, c->stream));  // halt, halt_topic, halt_sweep, halt_pos
+    HIPCHK(c, hipMemsetAsync(c->st, 0, 32, c->stream));  // halt, halt_topic, halt_sweep, halt_pos, tmode, proj_iters, sweep_base
     return RRI_OK;
 }
 
@@ -903,6 +962,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
+    if (const char* e = getenv("RRI_GRAPH")) g_graph = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
     if (const char* e = getenv("RRI_RESID_WAVES")) g_resid_waves = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
@@ -1023,6 +1083,7 @@ rri_status rri_destroy(rri_ctx* c) {
     if (!c) return RRI_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
     if (c->own_X) (void)hipFree(c->X);
     if (c->own_M) (void)hipFree(c->M);
     void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
@@ -1046,6 +1107,7 @@ rri_status rri_destroy(rri_ctx* c) {
 // ---- data ------------------------------------------------------------------------------------------
 rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->X && !c->own_X) c->X = nullptr;
@@ -1062,6 +1124,7 @@ rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_d
 
 rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1115,6 +1178,7 @@ rri_status csr_to_device(rri_ctx* c, const int64_t* indptr, const int32_t* indic
 rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
                             int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     HIPCHK(c, hipSetDevice(c->device));
     CsrDev dv;
@@ -1146,6 +1210,7 @@ rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* in
 rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
                                        int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1173,6 +1238,7 @@ rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const 
 rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* values,
                                    int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (!c->sparse) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=RRI_WEIGHTED_SPARSE");
     if (nnz >= 2147483647LL) return fail(c, RRI_ERR_UNSUPPORTED, "more than 2^31-1 observed entries");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1292,6 +1358,7 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
 
 rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
         return fail(c, RRI_ERR_INVALID, "device X must be 16-byte aligned with a 16-byte-multiple row stride >= d");
@@ -1311,6 +1378,7 @@ rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
 
 rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
@@ -1364,6 +1432,7 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
     if (p->fix_W && p->fix_T) return fail(c, RRI_ERR_INVALID, "fix_W and fix_T together leave nothing to update");
     c->prm = *p;
     c->have_params = true;
+    drop_graph(c);
     return RRI_OK;
 }
 
@@ -1379,6 +1448,61 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
     return status_from_halt(c, s, sweeps_done);
 }
 
+// launch-bound sizes only: where one streaming pass takes well under ~100 us the gaps between launches show
+static bool graph_wanted(const rri_ctx* c) {
+    if (g_graph == 0 || c->timing > 0) return false;
+    if (g_graph == 2) return true;
+    const double bytes = c->sparse ? 16.0 * (double)c->nnz : (double)c->n * (double)c->LD * (double)c->es;
+    return bytes <= 512e6;
+}
+
+static void enqueue_one_sweep(rri_ctx* c, int s) {   // as sweep 0 of DevState.sweep_base, then move that on
+    enqueue_range(c, Cursor{s, 0, 0}, s + 1, s);
+    hipLaunchKernelGGL(k_sweep_tick, dim3(1), dim3(1), 0, c->stream, c->st);
+}
+
+static rri_status sweep_with_graph(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int s = 0; s < n_sweeps; ++s) {
+        const SteadyState here = steady_of(c);
+        if (c->graph_exec && here == c->graph_entry) {
+            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+            restore_steady(c, c->graph_exit);
+            c->graph_replays += 1;
+            continue;
+        }
+        if (!c->graph_exec && s > 0) {
+            // capture the sweep that is due now; it is a steady-state sweep when it leaves the flags it found
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                enqueue_one_sweep(c, s);
+                ok = hipStreamEndCapture(c->stream, &g) == hipSuccess && g != nullptr;
+            }
+            const SteadyState after = steady_of(c);
+            if (ok && after == here && hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                c->graph_entry = here;
+                c->graph_exit = after;
+            } else {
+                c->graph_exec = nullptr;
+                ok = false;
+            }
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            restore_steady(c, here);          // nothing has run yet: the capture only recorded
+            if (ok) { --s; continue; }        // replay it for this sweep
+        }
+        enqueue_one_sweep(c, s);
+    }
+    enqueue_final_check(c, 0);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(c, RRI_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+    DevState st;
+    rri_status r = read_state(c, &st);
+    if (r != RRI_OK) return r;
+    return status_from_halt(c, st, sweeps_done);
+}
+
 rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
     CHECK_CTX(c);
     rri_status r = ready(c);
@@ -1388,6 +1512,7 @@ rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
     c->run_total = n_sweeps;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
+    if (n_sweeps > 0 && graph_wanted(c)) return sweep_with_graph(c, n_sweeps, sweeps_done);
     return run_and_collect(c, Cursor{0, 0, 0}, sweeps_done);
 }
 
@@ -1413,6 +1538,7 @@ static void event_resolved(rri_ctx* c) {
     if (c->pending.kind == RRI_EVENT_RESET_T) c->skip_row_finish = true;
     c->pending.kind = RRI_EVENT_NONE;
     if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
+    drop_graph(c);   // the kernels take resets_left by value
     invalidate(c);
 }
 
@@ -1457,6 +1583,7 @@ rri_status rri_skip_reset(rri_ctx* c) {
     if (!c->paused) return fail(c, RRI_ERR_INVALID, "no pending event");
     c->pending.kind = RRI_EVENT_NONE;
     c->prm.resets_left = 0;
+    drop_graph(c);
     rri_status r = clear_halt(c);
     if (r != RRI_OK) return r;
     return RRI_OK;
@@ -1736,6 +1863,7 @@ rri_status rri_reduce_buffer(rri_ctx* c, void** dev_ptr, int64_t* n_elems) {
 
 rri_status rri_bind_reduce_buffer(rri_ctx* c, void* dev_ptr, int64_t n_elems) {
     CHECK_CTX(c);
+    drop_graph(c);
     if (!dev_ptr || n_elems < c->red_elems || ((uintptr_t)dev_ptr) % 16)
         return fail(c, RRI_ERR_INVALID, "reduce buffer needs >= %lld elements, 16-byte aligned", c->red_elems);
     if (c->own_red && c->red) (void)hipFree(c->red);

@@ -42,7 +42,9 @@ struct DevState {
     int halt_pos;
     int tmode;       // qf_min branch of the current T row: 0 c>0, 1 c<=0 bounds, 2 c<=0 one-hot
     int proj_iters;  // Michelot iterations of the last projection (diagnostic)
-    int pad0, pad1;
+    int sweep_base;  // added to the `sweep` argument of every kernel: a captured sweep (hipGraph) is replayed with the
+                     // arguments it was captured with, k_sweep_tick moves this on after each replay
+    int pad1;
     double nt1;      // 1-norm of the unprojected T-row solution (qf_min's nx, nmf.py:447)
     double nt;       // ||T[t,:]||^2
     double sumT;
@@ -131,7 +133,7 @@ __device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ld
             st->nt1 = (mode == 0) ? ps : 1.0;
             st->sumT = ps;
             if (!(ps > 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0) {
-                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
             }
         }
     }
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
             if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;
             else {
                 if (blockIdx.x == 0 && tid == 0) {
-                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
                 }
                 return;
             }
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
         if (ev || err) {
             if (blockIdx.x == 0 && tid == 0) {
                 st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-                st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = t;
+                st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
             }
             return;
         }
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
         }
         if (mode < 0) {
             if (blockIdx.x == 0 && tid == 0) {
-                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
             }
             return;
         }
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(1024) void k_trow_final(double* __restrict__ T, i64
         st->nt1 = nx;
         st->sumT = sumT;
         st->proj_iters = iters;
-        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
+        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t; }
     }
 }
 
@@ -620,6 +622,12 @@ __global__ __launch_bounds__(256) void k_tgram(const double* __restrict__ T, i64
     if (st->halt) return;
     __shared__ double scratch[40];
     tgram_block(T, ldt, d, k, t, blockIdx.x, blockIdx.y, gridDim.y, Ttpart, tpart, nblk, finish, sweep, p, st, scratch);
+}
+
+// end of a captured sweep: the next replay reports its events one sweep later
+__global__ void k_sweep_tick(DevState* st) {
+    if (st->halt) return;
+    st->sweep_base += 1;
 }
 
 // W[:,t] *= nt1 (nmf.py:450-452); only observable when fix_W keeps the column.
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(64) void k_check_red(const double* __restrict__ red
         const bool err = !ev && !(sw > 0.0);
         if (ev || err) {
             st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+            st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
         }
     }
 }
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ G
         const bool err = !ev && !(a > 0.0);
         if (ev || err) {
             st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
+            st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
         }
     }
 }

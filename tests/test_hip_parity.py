@@ -381,3 +381,37 @@ def test_objective_without_a_pass_over_X(store, monkeypatch):
             e.update_T_row(1)                                # a lone half step: the cross terms are stale
             W, T = e.get_W(), e.get_T()
             assert abs(e.objective_parts()[0] - direct(W, T)) <= 1e-12 * direct(W, T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('weighted', [False, True])
+def test_captured_sweeps_equal_eager_sweeps(weighted, monkeypatch):
+    """RRI_GRAPH=2: steady-state sweeps are captured into a hipGraph and replayed (off by default: it does not pay on
+    this stack, csrc/rri_hip.hip); same launches, so the same bits -- including a reset event inside a replay"""
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = 1500, 420, 6
+    X = planted_X(n, d, k, seed=0, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    M = (np.random.RandomState(3).rand(n, d) < 0.3).astype(np.float64)
+    out = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('RRI_GRAPH', mode)
+        for flags in (dict(), dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0), dict(t_row_sum=1.0, reg_w_l1=1e6, n_resets=1000)):
+            if weighted:
+                flags = dict(flags, t_row_sum=1.0)
+                flags.pop('project_T_each_iter', None)
+            with RRIEngine(n, d, k, dtype=np.float64, weighted=weighted) as e:
+                e.upload_X(X * M if weighted else X)
+                if weighted:
+                    e.upload_mask(M)
+                e.set_W(W0), e.set_T(T0)
+                e.set_params(**flags)
+                e.sweep(4)
+                e.sweep(1)
+                o = e.objective()
+                e.sweep(3)
+                out[mode, tuple(sorted(flags))] = (e.get_W(), e.get_T(), o, e.n_resets_used)
+    for (mode, key), v in out.items():
+        if mode == '2':
+            ref = out['0', key]
+            assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]) and v[2] == ref[2] and v[3] == ref[3], key

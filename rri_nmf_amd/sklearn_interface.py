@@ -126,25 +126,43 @@ class NMF_RS_Estimator(_FactorPair, sklearn.base.BaseEstimator):
         return soln['W']
 
     def make_Xpred(self):
+        """the full clipped reconstruction, n x d dense (sklearn_interface.py:158-161): kept for callers that want it;
+        predict / score below evaluate only the entries they are asked for"""
         if self.Xpred.size == 0:
             self.Xpred = np.clip(np.dot(self.W, self.T), a_min=self.min_rating, a_max=self.max_rating)
 
+    def _predict_entries(self, i, j):
+        """clip(W T)[i, j] for index arrays i, j without forming the n x d product"""
+        if self.Xpred.size > 0:
+            return self.Xpred[i, j]
+        W = self.W.toarray() if sp.issparse(self.W) else self.W
+        T = self.T.toarray() if sp.issparse(self.T) else self.T
+        out = np.empty(len(i))
+        for lo in range(0, len(i), 1 << 20):          # chunks: the gathered rows are 2^20 x k doubles
+            sl = slice(lo, lo + (1 << 20))
+            out[sl] = np.einsum('ek,ke->e', W[i[sl], :], T[:, j[sl]])
+        return np.clip(out, self.min_rating, self.max_rating)
+
     def predict(self, X):
-        self.make_Xpred()
         X = check_array(X)
         # the reference indexes with the float array check_array returns, which modern numpy rejects
         idx = np.asarray(X, dtype=np.intp)
-        return self.Xpred[idx[:, 0], idx[:, 1]]
+        return self._predict_entries(idx[:, 0], idx[:, 1])
 
     def score(self, X, y=np.array([])):
-        """RMSE of the clipped reconstruction on the given entries"""
-        self.make_Xpred()
-        if sp.issparse(X):
-            X = X.toarray()
+        """RMSE of the clipped reconstruction on the given entries (sklearn_interface.py:172-182)"""
         if y.size > 0:
+            if sp.issparse(X):
+                X = X.toarray()
             return np.sqrt(np.mean((y - self.predict(X)) ** 2))
-        i, j = X.nonzero()
-        return np.sqrt(np.mean((X[i, j] - self.Xpred[i, j]) ** 2))
+        if sp.issparse(X):
+            C = X.tocoo()
+            keep = C.data != 0
+            i, j, v = C.row[keep], C.col[keep], C.data[keep]
+        else:
+            i, j = X.nonzero()
+            v = X[i, j]
+        return np.sqrt(np.mean((v - self._predict_entries(i, j)) ** 2))
 
 
 class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.TransformerMixin):

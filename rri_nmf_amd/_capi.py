@@ -96,6 +96,25 @@ class RRIHipUnavailable(RuntimeError):
     """librri_hip.so cannot be used here (not built, or no HIP device)."""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels ship their own libamdhip64; if this library pulls in the
+    system one first, a later torch.cuda initialisation finds "no HIP GPUs" (two runtimes in one process).  Loading
+    torch's copy first (without importing torch) makes the dynamic linker bind librri_hip.so to it as well -- the
+    order that has always worked, now independent of who imports what first.  RRI_HIP_OWN_RUNTIME=1 skips this."""
+    if os.environ.get('RRI_HIP_OWN_RUNTIME', '0') == '1':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001  (best effort: the system runtime is the fallback)
+        pass
+
+
 def load_library(path=None):
     """Opens librri_hip.so and types every entry point.  Raises RRIHipUnavailable
     if the file is missing; there is deliberately no fallback."""
@@ -107,6 +126,7 @@ def load_library(path=None):
         raise RRIHipUnavailable(
             'librri_hip.so not found at %s: build it with `python -m rri_nmf_amd.build` '
             '(needs hipcc; the RRI path has no CPU fallback)' % p)
+    _share_hip_runtime_with_torch()
     try:
         lib = C.CDLL(p)
     except OSError as e:  # e.g. libamdhip64 missing

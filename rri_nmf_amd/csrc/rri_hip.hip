@@ -398,6 +398,19 @@ struct LaunchX {
         hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
                            (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
     }
+    // column sums against NV = 8 row-vectors at once (Qt: 8 x n, stride ldw): out rows <- X^T q_v
+    static void colsums8(rri_ctx* c, const double* Qt, int nv, double* zmulti, double* out_rows) {
+        constexpr int NV = 8;
+        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        hipLaunchKernelGGL((k_colsums<SX, NV>), dim3(c->npanels * c->nrb), dim3(256), (size_t)NV * c->rpb * sizeof(double),
+                           c->stream, (const SX*)c->X, c->ldx, (int)c->n, ncols, Qt, c->ldw, nv, zmulti, c->LD, c->rpb,
+                           c->npanels, c->nrb);
+        const int nb = (int)((c->LD + 31) / 32);
+        for (int v = 0; v < nv; ++v)
+            hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream,
+                               (const double*)zmulti + (i64)v * c->nrb * c->LD, c->LD, c->nrb, (const double*)nullptr, 0,
+                               c->k, out_rows + (i64)v * c->LD, (const DevState*)c->st);
+    }
     static size_t resid_shmem(const rri_ctx* c) {
         return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
     }
@@ -1842,11 +1855,11 @@ rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
     const bool tm_on = c->timing != 0;
     const int tsave = c->timing;
     c->timing = 0;
-    for (int l = 0; l < m; ++l) {
-        DISPATCH(c, L::colsums(c, (const double*)qm.p + (i64)l * c->ldw));
-        HIPCHK(c, hipMemcpyAsync((double*)outm.p + (i64)l * c->LD, c->red, (size_t)c->LD * sizeof(double),
-                                 hipMemcpyDeviceToDevice, c->stream));
-    }
+    DevTmp zm;      // partial column sums of 8 vectors at a time: X is read once per 8 vectors
+    HIPCHK(c, zm.alloc((size_t)8 * c->nrb * c->LD * sizeof(double)));
+    for (int l = 0; l < m; l += 8)
+        DISPATCH(c, L::colsums8(c, (const double*)qm.p + (i64)l * c->ldw, std::min(8, m - l), (double*)zm.p,
+                                (double*)outm.p + (i64)l * c->LD));
     c->timing = tsave;
     (void)tm_on;
     invalidate(c);   // Zpart / red were used as scratch

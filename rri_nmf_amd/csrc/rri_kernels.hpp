@@ -254,6 +254,66 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
 }
 
 // =========================================================================================
+// k_colsums: column sums of X against NV row-vectors at once (X^T Q for the randomized SVD behind NNDSVD,
+// initialization.py:105): the geometry of k_pass -- 4 waves = 4 adjacent 1 KiB panels x a row block, 4 rows in
+// flight -- with NV accumulator sets per lane, so X is read once per NV vectors instead of once per vector.
+// Qt: the vectors as rows (NV x n, stride ldq).  Zmulti[v][row block][column], stride ldz.
+// =========================================================================================
+template <typename SX, int NV>
+__global__ __launch_bounds__(256) void k_colsums(const SX* __restrict__ X, i64 ldx, int n, int ncols,
+                                                 const double* __restrict__ Qt, i64 ldq, int nv,
+                                                 double* __restrict__ Zmulti, i64 ldz, int rpb, int npg, int nrb) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;
+    constexpr int PW = 64 * VN;
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* wsh = reinterpret_cast<double*>(smem);   // [NV][rpb]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const int row0 = rb * rpb, row1 = min(n, row0 + rpb);
+    const int col = (pg * 4 + wave) * PW + lane * VN;
+    for (int i = threadIdx.x; i < (row1 - row0) * NV; i += 256) {
+        const int v = i / (row1 - row0), r = i - v * (row1 - row0);
+        wsh[v * rpb + r] = v < nv ? Qt[(i64)v * ldq + row0 + r] : 0.0;
+    }
+    __syncthreads();
+    if ((pg * 4 + wave) * PW >= ncols) return;       // wave-uniform
+    const bool ok = col < ncols;
+    double acc[NV][VN];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[v][e] = 0.0;
+    for (int r = row0; r < row1; r += U) {
+        V x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            x[u] = (r + u < row1 && ok) ? stream_load<true>(reinterpret_cast<const V*>(X + (i64)(r + u) * ldx + col)) : XV::zero();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u >= row1) break;
+            double xe[VN];
+            XV::unpack(x[u], xe);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double wv = wsh[v * rpb + r + u - row0];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[v][e] = fma(wv, xe[e], acc[v][e]);
+            }
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) Zmulti[((i64)v * nrb + rb) * ldz + col + e] = acc[v][e];
+    }
+}
+
+// =========================================================================================
 // W is stored k-major on the device (Wt: k x ldw, ldw >= n): column t of W is the contiguous
 // row Wt[t,:], so the pass reads the active column coalesced and k_wcol needs no LDS staging.
 //

@@ -163,7 +163,9 @@ rri_status rri_rollback(rri_ctx* ctx);
 
 /* Products with the resident X for the initialisation (randomized SVD behind NNDSVD, initialization.py:105;
  * SURVEY 8f rank 2): out = X B (B: d x m host row-major, out: n x m) and out = X^T Q (Q: n x m, out: d x m),
- * float64 arithmetic on the stored X.  Blocking; not part of the sweep path. */
+ * float64 arithmetic on the stored X.  Blocking; not part of the sweep path.  On a pattern-only handle X is the
+ * matrix of the observed values (= W_mat .* X, what initialization.py:104 factorises for the weighted flavour)
+ * and m <= 64 per call. */
 rri_status rri_X_times(rri_ctx* ctx, const double* B, int32_t m, double* out);
 rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 

@@ -352,6 +352,17 @@ struct LaunchX {
         if (DO_Z || WRITE)   // segments = columns (b1, b2), gathered = rows (a1, a2, wc)
             sp_blk<DO_Z, UPD2, WRITE>(c, 1, a1, a2, wc, b1, b2, c->Zpart, c->Z2part, c->LD);
     }
+    // out (nseg x m, row-major, device) = the X on the pattern (which = 0) or its transpose (1) times B (gdim x m)
+    static void sp_spmm(rri_ctx* c, int which, const double* B, int m, double* part, double* out) {
+        const rri_ctx::SpCopy& cp = c->sp[which];
+        const i64 waves = (i64)cp.nblk * cp.nseg;
+        hipLaunchKernelGGL((k_sp_spmm<SX>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream,
+                           (const i64*)cp.segptr, cp.nseg, cp.nblk, (const unsigned short*)cp.idx, (const int*)cp.perm,
+                           (const SX*)c->sp_x, cp.bw, B, m, part);
+        const i64 count = cp.nseg * m;
+        hipLaunchKernelGGL(k_sp_sum_blocks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)part, count, cp.nblk, out);
+    }
     static void sp_resid(rri_ctx* c, bool write_e, double* rowobj, double* rowpos) {
         const i64 total = (i64)c->k * c->d;
         hipLaunchKernelGGL((k_convert2d<double, double, true>), dim3((unsigned)std::min<i64>(4096, (total + 255) / 256)),
@@ -1823,9 +1834,29 @@ rri_status rri_rollback(rri_ctx* c) {
 }
 
 // ---- products with X for the initialisation -------------------------------------------------------------------
+// out (nseg x m) = X B or X^T B on a pattern-only handle; B: gdim x m host row-major
+static rri_status sparse_times(rri_ctx* c, int which, const double* B, int32_t m, double* out) {
+    if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
+    if (!B || !out || m < 1 || m > 64) return fail(c, RRI_ERR_INVALID, "bad operand (1 <= m <= 64 columns on a pattern-only handle)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const rri_ctx::SpCopy& cp = c->sp[which];
+    // B is padded with zero rows up to nblk * bw so that a block's offsets always land inside it
+    const i64 brows = (i64)cp.nblk * cp.bw;
+    DevTmp bd, part, res;
+    HIPCHK(c, bd.alloc((size_t)brows * m * sizeof(double)));
+    HIPCHK(c, part.alloc((size_t)cp.nblk * cp.nseg * m * sizeof(double)));
+    HIPCHK(c, res.alloc((size_t)cp.nseg * m * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(bd.p, 0, (size_t)brows * m * sizeof(double), c->stream));
+    HIPCHK(c, hipMemcpyAsync(bd.p, B, (size_t)cp.gdim * m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DISPATCH(c, L::sp_spmm(c, which, (const double*)bd.p, m, (double*)part.p, (double*)res.p));
+    HIPCHK(c, hipMemcpyAsync(out, res.p, (size_t)cp.nseg * m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
 rri_status rri_X_times(rri_ctx* c, const double* B, int32_t m, double* out) {
     CHECK_CTX(c);
-    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
+    if (c->sparse) return sparse_times(c, 0, B, m, out);
     if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
     if (!B || !out || m < 1) return fail(c, RRI_ERR_INVALID, "bad operand");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1842,7 +1873,7 @@ rri_status rri_X_times(rri_ctx* c, const double* B, int32_t m, double* out) {
 
 rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
     CHECK_CTX(c);
-    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
+    if (c->sparse) return sparse_times(c, 1, Q, m, out);
     if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
     if (!Q || !out || m < 1) return fail(c, RRI_ERR_INVALID, "bad operand");
     HIPCHK(c, hipSetDevice(c->device));

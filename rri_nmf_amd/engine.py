@@ -299,6 +299,8 @@ class RRIEngine(object):
         B = np.ascontiguousarray(B, dtype=np.float64)
         if B.ndim != 2 or B.shape[0] != self.d:
             raise ValueError('operand must be (d, m)')
+        if self.sparse and B.shape[1] > 64:     # pattern-only handles take up to 64 columns per call
+            return np.hstack([self.X_times(B[:, lo:lo + 64]) for lo in range(0, B.shape[1], 64)])
         out = np.empty((self.n, B.shape[1]))
         self._check(self._lib.rri_X_times(self._h, B.ctypes.data_as(C.POINTER(C.c_double)), B.shape[1],
                                           out.ctypes.data_as(C.POINTER(C.c_double))))
@@ -309,6 +311,8 @@ class RRIEngine(object):
         Q = np.ascontiguousarray(Q, dtype=np.float64)
         if Q.ndim != 2 or Q.shape[0] != self.n:
             raise ValueError('operand must be (n, m)')
+        if self.sparse and Q.shape[1] > 64:
+            return np.hstack([self.Xt_times(Q[:, lo:lo + 64]) for lo in range(0, Q.shape[1], 64)])
         out = np.empty((self.d, Q.shape[1]))
         self._check(self._lib.rri_Xt_times(self._h, Q.ctypes.data_as(C.POINTER(C.c_double)), Q.shape[1],
                                            out.ctypes.data_as(C.POINTER(C.c_double))))

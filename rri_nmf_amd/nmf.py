@@ -178,7 +178,8 @@ def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, projec
         else:
             src = W_mat * X
         W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False,
-                              engine=engine if W_mat is None else None)
+                              # the device products see X (dense handles) or X on the pattern = W_mat .* X
+                              engine=engine if (W_mat is None or getattr(engine, 'sparse', False)) else None)
         if t_row_sum is not None:
             T = normalize(T) * t_row_sum
         if w_row_sum is not None:

@@ -153,3 +153,27 @@ def test_more_than_one_block_per_copy(n, d, store):
     tol = 1e-10 if store == np.float64 else 1e-3
     assert relfro(Ws, Wd) < tol and relfro(Ts, Td) < tol, (relfro(Ws, Wd), relfro(Ts, Td))
     assert abs(os_ - od) <= (1e-10 if store == np.float64 else 1e-5) * abs(od)
+
+
+def test_products_and_device_init_on_a_pattern_only_handle():
+    """rri_X_times / rri_Xt_times on the observed values (blocked copies, more than one block, more than 64 columns)
+    against scipy; nmf(init='nndsvd') of the weighted flavour started from them = started from scikit-learn's"""
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = 12500, 310, 5
+    X, M, _, _ = _problem(n, d, k, 0.1, seed=2)
+    A = sp.csr_matrix(M)
+    A.data = X[M > 0]
+    rs = np.random.RandomState(0)
+    for store in (np.float64, np.float32):
+        with RRIEngine(n, d, k, dtype=store, weighted='sparse') as e:
+            e.upload_observed_csr(A)
+            for m in (1, 15, 64, 70):
+                B, Q = rs.randn(d, m), rs.randn(n, m)
+                tol = 1e-13 if store == np.float64 else 1e-6
+                assert relfro(e.X_times(B), A.astype(store).astype(np.float64) @ B) < tol
+                assert relfro(e.Xt_times(Q), A.astype(store).astype(np.float64).T @ Q) < tol
+    kw = dict(max_iter=4, eps_stop=-1, t_row_sum=1.0, reset_topic_method=None, random_state=0)
+    a = nmf_mod.nmf(A, k, W_mat=sp.csr_matrix(M), device_init=True, **kw)
+    b = nmf_mod.nmf(A, k, W_mat=sp.csr_matrix(M), device_init=False, **kw)
+    assert relfro(a['W'], b['W']) < 1e-6 and relfro(a['T'], b['T']) < 1e-6, (relfro(a['W'], b['W']), relfro(a['T'], b['T']))

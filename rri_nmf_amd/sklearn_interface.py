@@ -234,8 +234,10 @@ class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.Tra
         return self.transform(X)
 
     def score(self, X, y=None):
-        """R^2 of the reconstruction of new documents"""
+        """R^2 of the reconstruction of new documents (sklearn_interface.py:339-345); the residual sum of squares
+        is taken on the device (rri_objective) instead of through an n x d product on the host"""
         sst = ((X - np.mean(X, axis=0)) ** 2).sum()
         W = self.transform(X)
-        sse = ((X - np.dot(W, self.T)) ** 2).sum()
+        calc = _nmf_module.TrueObjComputer(np.asarray(X), W, self.T, 0, 0, 0, 0, None, None)
+        sse = 2.0 * calc.true_objective()
         return 1 - sse / sst

@@ -249,6 +249,14 @@ def test_estimator_plumbing_with_oracle_solver(monkeypatch):
             kw['W_mat'] = kw['W_mat'].toarray()
         return orc.nmf(X, *a, **kw)
     monkeypatch.setattr(si._nmf_module, 'nmf', oracle_nmf)
+
+    class OracleObjective(object):                 # stands in for the device objective behind NMF_TM_Estimator.score
+        def __init__(self, X, W, T, *a, **kw):
+            self.v = orc.true_objective(X, W, T)
+
+        def true_objective(self):
+            return self.v
+    monkeypatch.setattr(si._nmf_module, 'TrueObjComputer', OracleObjective)
     g = load_golden('g1_tm_estimator')
     X = g['X']
     n, d = X.shape

@@ -108,6 +108,7 @@ struct rri_ctx {
     bool dt_pending = false;    // weighted: dtv holds a T-row change that E does not contain yet
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
     double *dtmp = nullptr;  // small double scratch (device): [0] sum, ...
+    double* objbuf = nullptr;   // W^T W | T T^T | cross terms of the objective assembled after a sweep
     i64* itmp = nullptr;     // small i64 scratch (device)
     i64* tpart_idx = nullptr;
     double *resetT = nullptr, *resetW = nullptr;  // staging for 'random' reset vectors
@@ -1067,6 +1068,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMemsetAsync(c->tpart, 0, (size_t)c->ntb * sizeof(double), c->stream));
     CR(hipMalloc((void**)&c->tpart_idx, (size_t)c->ntb * sizeof(i64)));
     CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
+    CR(hipMalloc((void**)&c->objbuf, (size_t)(2 * k * k + k) * sizeof(double)));
     CR(hipMalloc((void**)&c->dtmp, 16 * sizeof(double)));
     CR(hipMalloc((void**)&c->itmp, 16 * sizeof(i64)));
     if (weighted) {
@@ -1114,7 +1116,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -1682,7 +1684,9 @@ static rri_status norms_of(rri_ctx* c, const double* A, i64 rows, i64 cols, i64 
     return RRI_OK;
 }
 
-rri_status rri_objective_parts(rri_ctx* c, double out[3]) {
+// out = {data term, ||W||^2, ||W||_1}; tn (optional) = {., ||T||^2, ||T||_1}: everything rri_objective needs, with
+// ONE synchronisation on the path taken after a complete sweep
+static rri_status objective_terms(rri_ctx* c, double out[3], double* tn) {
     CHECK_CTX(c);
     if (!c->have_X || !c->have_W || !c->have_T) return fail(c, RRI_ERR_INVALID, "X, W, T must be set");
     if (c->weighted && !c->have_M) return fail(c, RRI_ERR_INVALID, "weighted handle without a mask");
@@ -1713,26 +1717,39 @@ rri_status rri_objective_parts(rri_ctx* c, double out[3]) {
             for (int b = 0; b < 256; ++b) c->x_sq += h[b];
             c->x_sq_valid = true;
         }
-        DevTmp g;
-        HIPCHK(c, g.alloc((size_t)(2 * k * k + k) * sizeof(double)));
-        double* gw = (double*)g.p;
+        double* gw = c->objbuf;
         double* gt = gw + k * k;
         double* xy = gt + k * k;
         hipLaunchKernelGGL(k_gram, dim3(k, k), dim3(256), 0, c->stream, (const double*)c->W, c->ldw, c->n, k, gw);
         hipLaunchKernelGGL(k_gram, dim3(k, k), dim3(256), 0, c->stream, (const double*)c->T, c->LD, c->d, k, gt);
         hipLaunchKernelGGL(k_rows_sum, dim3(k), dim3(256), 0, c->stream, (const double*)c->XYpart, c->nwb * WCOL_TILES, xy);
+        // ||.||^2 are the traces of the Gram matrices; the 1-norms are only needed with an l1 penalty
+        const bool need_l1 = c->prm.reg_w_l1 != 0.0 || c->prm.reg_t_l1 != 0.0 || !tn;
+        double hw[256 * 3], ht[256 * 3];
+        if (need_l1) {
+            LK::norms(c, c->W, c->k, c->n, c->ldw);
+            HIPCHK(c, hipMemcpyAsync(hw, c->normpart, sizeof hw, hipMemcpyDeviceToHost, c->stream));
+            if (tn) {
+                LK::norms(c, c->T, c->k, c->d, c->LD);
+                HIPCHK(c, hipMemcpyAsync(ht, c->normpart, sizeof ht, hipMemcpyDeviceToHost, c->stream));
+            }
+        }
         std::vector<double> h((size_t)(2 * k * k + k));
         HIPCHK(c, hipMemcpyAsync(h.data(), gw, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        double cross = 0.0, quad = 0.0;
+        double cross = 0.0, quad = 0.0, w2 = 0.0, t2 = 0.0;
         for (int t = 0; t < k; ++t) cross += h[(size_t)2 * k * k + t];
         for (int a = 0; a < k * k; ++a) quad += h[(size_t)a] * h[(size_t)k * k + a];
-        double nwv[3];
-        rri_status r2 = norms_of(c, c->W, c->k, c->n, c->ldw, nwv);
-        if (r2 != RRI_OK) return r2;
+        for (int t = 0; t < k; ++t) { w2 += h[(size_t)t * k + t]; t2 += h[(size_t)k * k + (size_t)t * k + t]; }
+        double w1 = 0.0, t1 = 0.0;
+        if (need_l1) {
+            for (int b = 0; b < 256; ++b) w1 += hw[3 * b + 2];
+            if (tn) for (int b = 0; b < 256; ++b) t1 += ht[3 * b + 2];
+        }
         out[0] = 0.5 * c->x_sq - cross + 0.5 * quad;
-        out[1] = nwv[1];
-        out[2] = nwv[2];
+        out[1] = w2;
+        out[2] = w1;
+        if (tn) { tn[0] = 0.0; tn[1] = t2; tn[2] = t1; }
         return RRI_OK;
     } else {
         DISPATCH(c, L::resid(c, false, false, c->rowobj, nullptr));
@@ -1748,17 +1765,17 @@ rri_status rri_objective_parts(rri_ctx* c, double out[3]) {
     out[0] = 0.5 * base;
     out[1] = nw[1];
     out[2] = nw[2];
+    if (tn) return norms_of(c, c->T, c->k, c->d, c->LD, tn);
     return RRI_OK;
 }
+
+rri_status rri_objective_parts(rri_ctx* c, double out[3]) { return objective_terms(c, out, nullptr); }
 
 rri_status rri_objective(rri_ctx* c, double* out) {
     CHECK_CTX(c);
     if (!out) return fail(c, RRI_ERR_INVALID, "out is NULL");
-    double parts[3];
-    rri_status r = rri_objective_parts(c, parts);
-    if (r != RRI_OK) return r;
-    double nt[3];
-    r = norms_of(c, c->T, c->k, c->d, c->LD, nt);
+    double parts[3], nt[3];
+    rri_status r = objective_terms(c, parts, nt);
     if (r != RRI_OK) return r;
     const rri_params& q = c->prm;
     // base + wr2 + tr2 + tr1 + wr1 (nmf.py:83-91)

@@ -17,4 +17,4 @@ for (n, d, k) in ((10000, 1000, 20), (2000, 500, 10), (20000, 5000, 20)):
                 e.sweep(1); e.objective()
             t2 = time.perf_counter() - t0
             print('RRI_GRAPH=%s %dx%d k=%d %-12s  sweep(200): %.1f sweeps/s   sweep(1)+objective loop: %.1f iterations/s   obj %.6e'
-                  % (os.environ.get('RRI_GRAPH', '1'), n, d, k, 'topic model' if flags else 'plain', 200 / t1, 100 / t2, e.objective()))
+                  % (os.environ.get('RRI_GRAPH', '0'), n, d, k, 'topic model' if flags else 'plain', 200 / t1, 100 / t2, e.objective()))

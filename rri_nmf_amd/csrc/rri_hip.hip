@@ -321,11 +321,12 @@ struct LaunchX {
                          const double* A1, const double* A2, double* S1, double* S2, i64 lds) {
         typedef typename SpTab<SX>::type TF;
         const size_t sh = 3 * (size_t)cp.bw * sizeof(TF);
-        static bool attr_set = false;   // per instantiation
-        if (!attr_set) {
+        static bool attr_set[64] = {};   // per instantiation and device (the attribute belongs to the device's code object)
+        const int dv = c->device & 63;
+        if (!attr_set[dv]) {
             (void)hipFuncSetAttribute((const void*)k_sp_blk<SX, DO_S, UPD2, WRITE, LPS>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SP_BLOCK_BYTES);
-            attr_set = true;
+            attr_set[dv] = true;
         }
         if (cp.nwork < 1) return;
         hipLaunchKernelGGL((k_sp_blk<SX, DO_S, UPD2, WRITE, LPS>), dim3(cp.nwork), dim3(1024), sh, c->stream,

@@ -38,6 +38,8 @@ extern "C" {
 #define RRI_ABI_VERSION 1
 /* the Gram part of the reduce buffer travels as this many slice sums (see rri_topic_reduce_local) */
 #define RRI_GRAM_SLICES 8
+/* largest rank k a handle takes */
+#define RRI_MAX_K 1024
 
 typedef struct rri_ctx rri_ctx; /* opaque */
 

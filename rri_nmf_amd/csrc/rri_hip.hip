@@ -424,8 +424,9 @@ struct LaunchX {
                                (const double*)zmulti + (i64)v * c->nrb * c->LD, c->LD, c->nrb, (const double*)nullptr, 0,
                                c->k, out_rows + (i64)v * c->LD, (const DevState*)c->st);
     }
+    static bool resid_w_resident(const rri_ctx* c) { return c->k <= 256; }   // 128 KiB of W tile at most
     static size_t resid_shmem(const rri_ctx* c) {
-        return ((size_t)c->k * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
+        return ((size_t)(resid_w_resident(c) ? c->k : 32) * 64 + 32 * 64) * sizeof(double) + 64 * 17 * sizeof(double);
     }
     static void resid(rri_ctx* c, bool masked, bool write_e, double* rowobj, double* rowpos) {
         if (c->sparse) { sp_resid(c, write_e, rowobj, rowpos); return; }   // outside the pattern nothing contributes
@@ -466,7 +467,8 @@ struct LaunchX {
 #define RRI_RESID(MK, WE)                                                                                       \
     hipLaunchKernelGGL((k_resid<SX, MK, WE>), dim3(nb), dim3(256), sh, c->stream, (const SX*)c->X, c->ldx,      \
                        (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,   \
-                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD,       \
+                       resid_w_resident(c) ? 1 : 0)
         if (masked && write_e) RRI_RESID(true, true);
         else if (masked) RRI_RESID(true, false);
         else if (write_e) RRI_RESID(false, true);
@@ -972,7 +974,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (n < 1 || d < 1 || k < 1) return fail(nullptr, RRI_ERR_INVALID, "need n,d,k >= 1 (got %lld,%lld,%d)", n, d, k);
     if (dtype != RRI_F32 && dtype != RRI_F64) return fail(nullptr, RRI_ERR_INVALID, "dtype must be RRI_F32/RRI_F64");
     if (n > 2000000000LL || d > 2000000000LL) return fail(nullptr, RRI_ERR_INVALID, "n, d must fit int32");
-    if (k > 256) return fail(nullptr, RRI_ERR_UNSUPPORTED, "k=%d > 256 not supported on the device path", k);
+    if (k > RRI_MAX_K) return fail(nullptr, RRI_ERR_UNSUPPORTED, "k=%d > %d not supported on the device path", k, RRI_MAX_K);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, RRI_ERR_HIP, "no HIP device available (librri_hip needs an MI355X)");

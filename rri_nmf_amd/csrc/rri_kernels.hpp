@@ -504,7 +504,7 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
     if (st->halt) return;
     const int tid = threadIdx.x;
     __shared__ double scratch[40];
-    __shared__ double gsh[256];
+    __shared__ double gsh[RRI_MAX_K];
     const double nw = red_gram(red, ldz, k, k);
     if (check_prev) {
         const double sw = red_gram(red, ldz, k, k + 1);
@@ -769,19 +769,23 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
                                                const unsigned* __restrict__ Mb, i64 ldb,
                                                const double* __restrict__ Wt, i64 ldw, const double* __restrict__ T,
                                                i64 ldt, int n, int d, int k, double* __restrict__ rowobj,
-                                               double* __restrict__ rowpos, SX* __restrict__ E, i64 lde) {
+                                               double* __restrict__ rowpos, SX* __restrict__ E, i64 lde,
+                                               int w_resident) {
     typedef double S;
     constexpr int KC = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    S* Wsh = reinterpret_cast<S*>(smem);          // [k][64]  (transposed tile of W)
-    S* Tsh = Wsh + (size_t)k * 64;                 // [KC][64]
+    // w_resident: the whole 64-row tile of W (k x 64) stays in LDS for all column tiles (k <= 256); otherwise only a
+    // KC-topic slice at a time, reloaded per column tile (large k: correctness path, L2 traffic n k 8 per column tile)
+    S* Wsh = reinterpret_cast<S*>(smem);          // [k or KC][64]  (transposed tile of W)
+    S* Tsh = Wsh + (size_t)(w_resident ? k : KC) * 64;   // [KC][64]
     double* red = reinterpret_cast<double*>(Tsh + KC * 64);  // [64][17]
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const i64 row0 = (i64)blockIdx.x * 64;
-    for (int idx = tid; idx < 64 * k; idx += 256) {
-        const int l = idx >> 6, r = idx & 63;
-        Wsh[l * 64 + r] = (row0 + r < n) ? Wt[(i64)l * ldw + row0 + r] : S(0);
-    }
+    if (w_resident)
+        for (int idx = tid; idx < 64 * k; idx += 256) {
+            const int l = idx >> 6, r = idx & 63;
+            Wsh[l * 64 + r] = (row0 + r < n) ? Wt[(i64)l * ldw + row0 + r] : S(0);
+        }
     double so[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
     for (i64 c0 = 0; c0 < d; c0 += 64) {
         S acc[4][4];
@@ -795,12 +799,14 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
             for (int idx = tid; idx < kc * 64; idx += 256) {
                 const int l = idx >> 6, c = idx & 63;
                 Tsh[l * 64 + c] = (c0 + c < d) ? T[(i64)(l0 + l) * ldt + c0 + c] : S(0);
+                if (!w_resident) Wsh[l * 64 + c] = (row0 + c < n) ? Wt[(i64)(l0 + l) * ldw + row0 + c] : S(0);
             }
             __syncthreads();
+            const int wbase = w_resident ? l0 : 0;
             for (int l = 0; l < kc; ++l) {
                 S wv[4], tv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) wv[a] = Wsh[(l0 + l) * 64 + ty * 4 + a];
+                for (int a = 0; a < 4; ++a) wv[a] = Wsh[(wbase + l) * 64 + ty * 4 + a];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) tv[b] = Tsh[l * 64 + tx * 4 + b];
 #pragma unroll

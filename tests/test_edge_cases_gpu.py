@@ -72,6 +72,13 @@ CASES = {
     'weighted_W_col_resets': lambda: (rnd(0, 60, 40) * (rnd(5, 60, 40) < 0.5), 3, rnd(1, 60, 3), rnd(2, 3, 40),
                                       dict(max_iter=2, W_mat=(rnd(5, 60, 40) < 0.5).astype(float), t_row_sum=1.0,
                                            reg_w_l1=1e6, reset_topic_method='max_resid_document')),
+    'k300_past_the_resident_W_tile': lambda: (rnd(0, 420, 350), 300, rnd(1, 420, 300) * 0.1, rnd(2, 300, 350) * 0.1,
+                                              dict(max_iter=2, compute_obj_each_iter=True)),
+    'k1000_topic_model': lambda: (rnd(0, 90, 1100), 1000, rnd(1, 90, 1000) * 0.05, rnd(2, 1000, 1100) * 0.05,
+                                  dict(max_iter=1, project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'k300_weighted': lambda: (rnd(0, 350, 200) * (rnd(5, 350, 200) < 0.5), 300, rnd(1, 350, 300) * 0.1, rnd(2, 300, 200) * 0.1,
+                              dict(max_iter=1, W_mat=(rnd(5, 350, 200) < 0.5).astype(float), t_row_sum=1.0,
+                                   reset_topic_method=None)),
     'fp32_input_ragged_d': lambda: (rnd(0, 130, 1027).astype(np.float32), 5, rnd(1, 130, 5), rnd(2, 5, 1027),
                                     dict(max_iter=3)),
 }

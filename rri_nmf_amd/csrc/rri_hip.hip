@@ -115,6 +115,8 @@ struct rri_ctx {
     DevState* st = nullptr;
 
     int npanels = 1, rpb = 1, nrb = 1, nwb = 1, ntb = 1;
+    int ntb32 = 1;     // 32-column blocks of k_trow_small
+    int tpart_n = 1;   // entries the last T-row step left in tpart (128- or 32-column blocks)
 
     rri_params prm{};
     bool have_params = false, have_X = false, have_W = false, have_T = false, have_M = false;
@@ -241,6 +243,7 @@ int g_resid_waves = 4;  // RRI_RESID_WAVES=8: 128-row instead of 64-row workgrou
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
 int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
                         // launch-bound sizes, 2 always
+int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
@@ -539,9 +542,24 @@ struct LK {  // float64-only kernels
         hipLaunchKernelGGL(k_trow_numer, dim3(c->ntb), dim3(128), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, check_prev, tprev, sweep,
                            kparams(c), c->st);
+        c->tpart_n = c->ntb;
+        trow_final_if_needed(c, t, sweep, force_final);
+    }
+    // launch-bound sizes: k_reduce and k_trow_numer as one launch (every workgroup reduces the Gram partials itself)
+    static bool small(const rri_ctx* c) {
+        return g_trow_small && (double)c->nwb * (c->k + 2) * c->ntb32 <= 4.0e6;
+    }
+    static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
+        hipLaunchKernelGGL(k_trow_small, dim3(c->ntb32), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
+                           (const double*)c->Zpart, c->nrb, (const double*)c->Gpart, c->nwb, c->red, c->LD, c->xraw,
+                           c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st);
+        c->tpart_n = c->ntb32;
+        trow_final_if_needed(c, t, sweep, force_final);
+    }
+    static void trow_final_if_needed(rri_ctx* c, int t, int sweep, bool force_final) {
         if (!light(c) || force_final)
             hipLaunchKernelGGL(k_trow_final, dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t, c->xraw,
-                               (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, sweep, kparams(c), c->st);
+                               (const double*)c->tpart, (const i64*)c->tpart_idx, c->tpart_n, sweep, kparams(c), c->st);
     }
     static void check_prev_only(rri_ctx* c, int tprev, int sweep, int pos) {
         hipLaunchKernelGGL(k_check_red, dim3(1), dim3(64), 0, c->stream, (const double*)c->red, c->LD, c->k, tprev,
@@ -549,7 +567,7 @@ struct LK {  // float64-only kernels
     }
     static void tgram(rri_ctx* c, int t, int finish, int sweep) {
         hipLaunchKernelGGL(k_tgram, dim3(c->k, c->nsplit), dim3(256), 0, c->stream, (const double*)c->T, c->LD,
-                           (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->ntb, finish, sweep,
+                           (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n, finish, sweep,
                            kparams(c), c->st);
     }
     static void scale_wcol(rri_ctx* c, int t) {
@@ -704,9 +722,13 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     if (!c->carry_valid || c->carry_topic != t) enqueue_prologue(c, t, sweep);
     {
         TimedScope ts(c, 2);
-        LK::reduce(c);
         const int chk = c->pending_wcheck ? 1 : 0;
-        LK::trow(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
+        if (LK::small(c)) {
+            LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
+        } else {
+            LK::reduce(c);
+            LK::trow(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
+        }
         c->pending_wcheck = false;
         if (c->prm.fix_W && no_regs(c)) LK::scale_wcol(c, t);
     }
@@ -729,7 +751,7 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
         TimedScope ts(c, 2);
         LK::tgram(c, t, finish, sweep);
     } else {
-        job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->ntb,
+        job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n,
                        c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
     }
     if (carry_next) {
@@ -990,6 +1012,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
+    if (const char* e = getenv("RRI_TROW_SMALL")) g_trow_small = atoi(e) != 0;
     if (const char* e = getenv("RRI_GRAPH")) g_graph = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
     if (const char* e = getenv("RRI_RESID_WAVES")) g_resid_waves = atoi(e) == 8 ? 8 : 4;
@@ -1042,6 +1065,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->nwb = (int)((n + 64 * WCOL_TILES - 1) / (64 * WCOL_TILES));   // k_wcol blocks = rows of Gpart
     c->nwb256 = (int)((n + 255) / 256);
     c->ntb = (int)((d + 127) / 128);
+    c->ntb32 = (int)((c->LD + 31) / 32);
+    c->tpart_n = c->ntb;
     c->ldw = n;
     c->nsplit = (int)std::max<i64>(1, std::min<i64>(8, d / 2048));
     c->red_elems = round_up(std::max<i64>(c->LD + (i64)GRAM_SLICES * (k + 2), weighted ? 2 * c->LD + 2 : 0), 4);
@@ -1067,9 +1092,10 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMalloc((void**)&c->Ttpart, (size_t)c->nsplit * k * f8));
     CR(hipMemsetAsync(c->Ttpart, 0, (size_t)c->nsplit * k * f8, c->stream));
     CR(hipMalloc((void**)&c->Qt, (size_t)k * c->ldw * f8));
-    CR(hipMalloc((void**)&c->tpart, (size_t)c->ntb * sizeof(double)));
-    CR(hipMemsetAsync(c->tpart, 0, (size_t)c->ntb * sizeof(double), c->stream));
-    CR(hipMalloc((void**)&c->tpart_idx, (size_t)c->ntb * sizeof(i64)));
+    const size_t ntp = (size_t)std::max(c->ntb, c->ntb32);
+    CR(hipMalloc((void**)&c->tpart, ntp * sizeof(double)));
+    CR(hipMemsetAsync(c->tpart, 0, ntp * sizeof(double), c->stream));
+    CR(hipMalloc((void**)&c->tpart_idx, ntp * sizeof(i64)));
     CR(hipMalloc((void**)&c->normpart, 256 * 3 * sizeof(double)));
     CR(hipMalloc((void**)&c->objbuf, (size_t)(2 * k * k + k) * sizeof(double)));
     CR(hipMalloc((void**)&c->dtmp, 16 * sizeof(double)));

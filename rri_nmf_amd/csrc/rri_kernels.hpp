@@ -581,6 +581,122 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
     if (blockIdx.x == 0 && tid == 0) st->tmode = mode;
 }
 
+// =========================================================================================
+// k_trow_small: k_reduce and k_trow_numer in ONE launch, for problems small enough that every workgroup can afford
+// to reduce the Gram partials itself (nwb (k+2) doubles, L2-resident): launch-bound sizes lose a dependent launch per
+// topic step.  Block = 32 columns x 32 groups (1024 threads): the groups share the row blocks of Zpart for the column
+// sums, the Gpart rows for the Gram entries and the topics for (w^T W)_{-t} T; partials meet in LDS and are added in a
+// fixed order.  Also writes red (columns and slice 0 of the Gram part, the other slices zero), so whoever reads the
+// reduce buffer afterwards sees what k_reduce would have left up to the order of the sums.
+// tpart / tpart_idx then hold one entry per 32 columns.
+// =========================================================================================
+__global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64 ldt, int d, int k, int t,
+                                                     const double* __restrict__ Zpart, int nrb,
+                                                     const double* __restrict__ Gpart, int nwb, double* __restrict__ red,
+                                                     i64 ldz, double* __restrict__ xraw, double* __restrict__ tpart,
+                                                     i64* __restrict__ tpart_idx, int check_prev, int tprev, int sweep,
+                                                     KParams p, DevState* st) {
+    if (st->halt) return;
+    const int tid = threadIdx.x;
+    __shared__ double sh[32 * 33];
+    __shared__ double gsh[RRI_MAX_K + 2];
+    __shared__ double zs[32];
+    const int cc = tid & 31, g = tid >> 5;
+    // Gram entries [w^T W (k) | ||w||^2 | sum W[:,tprev]]: 32 groups over the Gpart rows, 32 entries per round
+    for (int l0 = 0; l0 < k + 2; l0 += 32) {
+        const int l = l0 + cc;
+        double a = 0.0;
+        if (l < k + 2)
+            for (int b = g; b < nwb; b += 32) a += Gpart[(i64)b * (k + 2) + l];
+        __syncthreads();
+        sh[g * 33 + cc] = a;
+        __syncthreads();
+        if (tid < 32 && l < k + 2) {
+            double s = 0.0;
+            for (int q = 0; q < 32; ++q) s += sh[q * 33 + tid];
+            gsh[l] = s;
+        }
+    }
+    __syncthreads();
+    const double nw = gsh[k];
+    if (check_prev) {
+        const double sw = gsh[k + 1];
+        const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(sw > 0.0);
+        if (ev || err) {
+            if (blockIdx.x == 0 && tid == 0) {
+                st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+                st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+            }
+            return;
+        }
+    }
+    const double c = nw + p.reg_t_l2;  // denom = nw + reg_t_l2 (nmf.py:438)
+    const bool project = p.project_T && p.has_trs;
+    int mode = 0;
+    if (!(c > 0.0)) {
+        if (!project) {
+            if (p.has_trs && p.t_row_sum != 0.0) mode = 1;
+            else mode = HALT_ERR_UNBOUNDED;
+        } else {
+            mode = (p.t_row_sum == 1.0) ? 2 : HALT_ERR_NOT_IMPLEMENTED;
+        }
+        if (mode < 0) {
+            if (blockIdx.x == 0 && tid == 0) {
+                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+            }
+            return;
+        }
+    }
+    if (blockIdx.x == 0)   // the reduce buffer as k_reduce leaves it: slice 0 carries the sums, the rest zeros
+        for (int i = tid; i < GRAM_SLICES * (k + 2); i += 1024) red[ldz + i] = i < k + 2 ? gsh[i] : 0.0;
+    const i64 j = (i64)blockIdx.x * 32 + cc;
+    {
+        double a = 0.0;
+        if (j < ldz)
+            for (int b = g; b < nrb; b += 32) a += Zpart[(i64)b * ldz + j];
+        sh[g * 33 + cc] = a;
+    }
+    __syncthreads();
+    if (tid < 32) {   // here cc == tid
+        double s = 0.0;
+        for (int q = 0; q < 32; ++q) s += sh[q * 33 + tid];
+        zs[tid] = s;
+        if (j < ldz) red[j] = s;
+    }
+    __syncthreads();
+    {
+        double a = 0.0;
+        if (j < d)
+            for (int l = g; l < k; l += 32)
+                if (l != t) a = fma(gsh[l], T[(i64)l * ldt + j], a);
+        sh[g * 33 + cc] = a;
+    }
+    __syncthreads();
+    if (tid < 64) {   // wave 0; lanes 0..31 own a column each
+        double x = 0.0, mx = -1.0e300;
+        i64 idx = (i64)0x7fffffffffffffffLL;
+        if (tid < 32 && j < d) {
+            double acc = 0.0;
+            for (int q = 0; q < 32; ++q) acc += sh[q * 33 + tid];
+            const double numer = (zs[tid] - acc) - p.reg_t_l1;
+            if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
+            else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
+            else { x = numer; mx = numer; idx = j; }
+            xraw[j] = x;
+            if (mode == 1 || (mode == 0 && !project)) T[(i64)t * ldt + j] = x;
+        }
+        if (mode != 2) {
+            const double s = wave_sum<double>(x);
+            if (tid == 0) tpart[blockIdx.x] = s;
+        } else {
+            wave_argmax(mx, idx);
+            if (tid == 0) { tpart[blockIdx.x] = mx; tpart_idx[blockIdx.x] = idx; }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) st->tmode = mode;
+}
+
 // Michelot's fixed point for the Euclidean simplex projection (same active set, hence the same
 // theta = (sum_active - s)/|active|, as the sort of matrixops.py:58-63).  Single workgroup.
 __device__ inline double simplex_theta(const double* v, int d, double s, double* scratch, int* iters) {

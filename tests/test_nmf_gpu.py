@@ -186,7 +186,9 @@ def test_sharded_stepping_single_rank_matches_sweep():
         eng.close()
     finally:
         dist.destroy_process_group()
-    assert np.array_equal(Wa, Wb) and np.array_equal(Ta, Tb)
+    # same arithmetic up to the order of the small sums: at launch-bound sizes rri_sweep fuses k_reduce and
+    # k_trow_numer into one launch (k_trow_small), the split protocol keeps them apart
+    assert relfro(Wa, Wb) < 1e-13 and relfro(Ta, Tb) < 1e-13
     assert abs(obja - objb) <= 1e-12 * abs(obja)
 
 

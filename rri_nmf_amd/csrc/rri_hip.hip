@@ -1034,17 +1034,27 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
 
     // geometry of the streaming pass
     c->npanels = (int)((c->LD + c->PW - 1) / c->PW);
-    int target = 2048;
-    if (const char* e = getenv("RRI_PASS_WGS")) target = std::max(1, atoi(e));
-    int nrb_t = std::max(1, target / c->npanels);
-    i64 rpb = (n + nrb_t - 1) / nrb_t;
+    // Workgroups: a multiple of 512 (2 per CU: with 525 on 256 CUs some CUs get three and the pass waits for them),
+    // as many as possible up to 2048 while each still walks ~192 rows or more -- with 49 rows each (20000 x 5000 at
+    // 2048 workgroups) ramp-up and tail cost 13 % of the pass (profiles/r01_pass_workgroups_mid_size.log).
+    // LDS per workgroup = (6 rows-doubles plain | 11 weighted) * rpb + 4 row-sum tiles (18 KiB): kept under 40 KiB so
+    // that 4 workgroups (16 waves) fit a CU's 160 KiB -- with 62 KiB the weighted passes ran at 2 workgroups per CU
+    // and 20 % slower.
+    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : 6) * 8)) / 16 * 16;
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
+    i64 rpb = 0;
+    if (const char* e = getenv("RRI_PASS_WGS")) {
+        const int nrb_t = std::max(1, std::max(1, atoi(e)) / c->npanels);
+        rpb = (n + nrb_t - 1) / nrb_t;
+    } else {
+        for (int total = 2048; total >= 512 && rpb == 0; total -= 512) {
+            const int nrb_t = std::max(1, total / c->npanels);
+            const i64 r = (n + nrb_t - 1) / nrb_t;
+            if (r >= 192 || total == 512) rpb = r;
+        }
+    }
     rpb = std::max<i64>(rpb, rpb_min);
-    // LDS per workgroup = (6 rows-doubles plain | 11 weighted) * rpb + 4 row-sum tiles (18 KiB): keep it under
-    // 40 KiB so that 4 workgroups (16 waves) fit a CU's 160 KiB -- with 62 KiB the weighted passes ran at 2
-    // workgroups per CU and 20 % slower
-    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : 6) * 8)) / 16 * 16;
     rpb = std::min<i64>(round_up(rpb, 16), rpb_cap);
     c->rpb = (int)rpb;
     c->nrb = (int)((n + rpb - 1) / rpb);

@@ -250,14 +250,15 @@ int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the re
 template <typename SX>
 struct LaunchX {
     typedef SX Elem;
-    static size_t pass_shmem(const rri_ctx* c) { return (6 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
+    // row-dot slots of the 4 waves, the active W column, (UPD: the rank-one row factors,) the row-sum tiles
+    static size_t pass_shmem(const rri_ctx* c, bool upd) { return ((upd ? 6 : 5) * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
     template <bool DO_Y, bool DO_Z, bool UPD, int U, bool NT, bool RS>
     static void pass_k(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b,
                        const TgramJob& job) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
         typedef typename std::conditional<UPD, SX, const SX>::type XT;
         hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
-                           pass_shmem(c), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
+                           pass_shmem(c, UPD), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
                            c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st, job);
     }
     template <bool DO_Y, bool DO_Z, bool UPD>
@@ -1037,10 +1038,10 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     // Workgroups: a multiple of 512 (2 per CU: with 525 on 256 CUs some CUs get three and the pass waits for them),
     // as many as possible up to 2048 while each still walks ~192 rows or more -- with 49 rows each (20000 x 5000 at
     // 2048 workgroups) ramp-up and tail cost 13 % of the pass (profiles/r01_pass_workgroups_mid_size.log).
-    // LDS per workgroup = (6 rows-doubles plain | 11 weighted) * rpb + 4 row-sum tiles (18 KiB): kept under 40 KiB so
+    // LDS per workgroup = (5 rows-doubles plain | 11 weighted) * rpb + 4 row-sum tiles (18 KiB): kept under 40 KiB so
     // that 4 workgroups (16 waves) fit a CU's 160 KiB -- with 62 KiB the weighted passes ran at 2 workgroups per CU
-    // and 20 % slower.
-    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : 6) * 8)) / 16 * 16;
+    // and 20 % slower.  (The explicit update kernel takes a sixth array and may run at 3 per CU.)
+    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : 5) * 8)) / 16 * 16;
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
     i64 rpb = 0;

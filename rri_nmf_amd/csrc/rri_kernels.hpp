@@ -166,11 +166,11 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ysh = reinterpret_cast<double*>(smem);            // [4 waves][rpb]
     double* wsh = ysh + 4 * rpb;                              // [rpb]
-    double* ash = wsh + rpb;                                  // [rpb] (UPD)
+    double* ash = wsh + rpb;                                  // [rpb], only with UPD
     static_assert(!RS || U == 8, "the LDS row-sum path reduces 8 rows at a time");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* tile = ash + rpb + wave * (8 * 72);               // [4][8*72] private row-sum tiles (RS)
+    double* tile = wsh + (UPD ? 2 : 1) * rpb + wave * (8 * 72);   // [4][8*72] private row-sum tiles (RS)
     const int pg = bid % npg;
     const int rb = bid / npg;
     const int row0 = rb * rpb;

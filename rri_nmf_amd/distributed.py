@@ -61,6 +61,12 @@ class ShardedRRI(object):
         # collective waits for k_reduce and k_trow_numer waits for the collective
         return torch.cuda.stream(self.stream)
 
+    def _sync(self):
+        """the host is about to read what a collective on the engine's stream produced: RCCL only orders the
+        collective against that stream, not against the host or torch's default stream"""
+        if self.stream is not None:
+            self.stream.synchronize()
+
     def _allreduce(self):
         with self._on_stream():
             self.dist.all_reduce(self.red, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -74,6 +80,12 @@ class ShardedRRI(object):
 
     # ---- resets ------------------------------------------------------------------------------------
     def _resolve(self, t):
+        # every torch operation below runs on the ENGINE's stream (fills, copies, collectives): tensors made on
+        # torch's default stream would race with the collectives, which are ordered against the engine's stream only
+        with self._on_stream():
+            self._resolve_on_stream(t)
+
+    def _resolve_on_stream(self, t):
         import torch
         dist, dev = self.dist, self.red.device
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
@@ -83,16 +95,16 @@ class ShardedRRI(object):
             val, idx = self.eng.resid_row_argmax()
             mine = torch.tensor([val, float(self.row_lo + idx)], dtype=torch.float64, device=dev)
             allv = [torch.zeros_like(mine) for _ in range(world)]
-            with self._on_stream():
-                dist.all_gather(allv, mine, group=self.group)
+            dist.all_gather(allv, mine, group=self.group)
+            self._sync()
             cand = [(float(v[0]), int(v[1]), r) for r, v in enumerate(allv)]
             best = max(c[0] for c in cand)
             winner = min((c for c in cand if c[0] == best), key=lambda c: c[1])   # first index of the maximum
             row = torch.zeros(d, dtype=torch.float64, device=dev)
             if rank == winner[2]:
                 row.copy_(torch.from_numpy(self.eng.reset_row(idx)))
-            with self._on_stream():
-                dist.broadcast(row, src=winner[2], group=self.group)
+            dist.broadcast(row, src=winner[2], group=self.group)
+            self._sync()
             wcol = np.zeros(n_local)
             if rank == winner[2]:
                 wcol[idx] = 1.0
@@ -106,8 +118,8 @@ class ShardedRRI(object):
                 trow = np.random.rand(1, d)
                 trow = (trow / trow.sum()).ravel()
                 buf.copy_(torch.from_numpy(np.concatenate([trow, np.random.rand(n_global)])))
-            with self._on_stream():
-                dist.broadcast(buf, src=0, group=self.group)
+            dist.broadcast(buf, src=0, group=self.group)
+            self._sync()
             h = buf.cpu().numpy()
             self.eng.apply_reset_vectors(t, h[:d], h[d + self.row_lo:d + self.row_lo + n_local])
         else:
@@ -158,9 +170,10 @@ class ShardedRRI(object):
     def objective(self, reg_w_l1=0.0, reg_w_l2=0.0, reg_t_l1=0.0, reg_t_l2=0.0, t_norms=None):
         """true_objective (nmf.py:71-94) of the global problem: row terms summed over the ranks"""
         import torch
-        parts = torch.tensor(self.eng.objective_parts(), dtype=torch.float64, device=self.red.device)
         with self._on_stream():
+            parts = torch.tensor(self.eng.objective_parts(), dtype=torch.float64, device=self.red.device)
             self.dist.all_reduce(parts, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._sync()
         base, w2, w1 = [float(v) for v in parts.cpu()]
         t2, t1 = t_norms if t_norms is not None else self.eng.t_norms()
         return base + 0.5 * reg_w_l2 * w2 + 0.5 * reg_t_l2 * t2 + reg_t_l1 * t1 + reg_w_l1 * w1

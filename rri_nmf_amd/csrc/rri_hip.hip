@@ -403,7 +403,31 @@ struct LaunchX {
         err = hipStreamSynchronize(c->stream);
         return err == hipSuccess ? RRI_OK : RRI_ERR_HIP;
     }
+    template <int NT>
+    static void xtt_mfma_k(rri_ctx* c, const double* Tm, int m, double* out) {
+        constexpr int VN = XVec<SX>::N;
+        const size_t sh = 2 * 64 * (size_t)(16 * NT + 1) * sizeof(double) + 4 * 16 * (size_t)(64 + VN) * sizeof(SX);
+        static bool attr_set[64] = {};
+        if (!attr_set[c->device & 63]) {
+            (void)hipFuncSetAttribute((const void*)k_xtt_mfma<SX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[c->device & 63] = true;
+        }
+        hipLaunchKernelGGL((k_xtt_mfma<SX, NT>), dim3((unsigned)((c->n + 63) / 64)), dim3(256), sh, c->stream,
+                           (const SX*)c->X, c->ldx, Tm, c->LD, (int)c->n, (int)c->d, m, out, c->ldw);
+    }
     static void xtt_any(rri_ctx* c, const double* Tm, int m, double* out) {   // out (m x n) = (X Tm^T)^T
+        if (g_resid_mfma) {   // the product on the matrix cores, up to 64 rows of Tm per launch
+            for (int l0 = 0; l0 < m; l0 += 64) {
+                const int mm = std::min(64, m - l0);
+                const double* Tp = Tm + (i64)l0 * c->LD;
+                double* op = out + (i64)l0 * c->ldw;
+                if (mm <= 16) xtt_mfma_k<1>(c, Tp, mm, op);
+                else if (mm <= 32) xtt_mfma_k<2>(c, Tp, mm, op);
+                else if (mm <= 48) xtt_mfma_k<3>(c, Tp, mm, op);
+                else xtt_mfma_k<4>(c, Tp, mm, op);
+            }
+            return;
+        }
         hipLaunchKernelGGL((k_xtt<SX>), dim3((unsigned)((c->n + 63) / 64)), dim3(256), 0, c->stream, (const SX*)c->X,
                            c->ldx, Tm, c->LD, (int)c->n, (int)c->d, m, out, c->ldw);
     }

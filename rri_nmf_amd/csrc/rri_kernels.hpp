@@ -1174,6 +1174,114 @@ __global__ __launch_bounds__(256) void k_xtt(const SX* __restrict__ X, i64 ldx, 
     }
 }
 
+// =========================================================================================
+// k_xtt_mfma: Qt = (X Tm^T)^T for up to 64 rows of Tm (topics, or the columns of a dense operand) on the matrix
+// cores: D(16 rows of X x 16 topics) += A(16 rows x 4 columns of X) * B(4 columns x 16 topics), f64 MFMA 16x16x4.
+// Wave w of the block owns rows 16w .. 16w+15.  Per step of 64 columns:
+//   * the wave's X tile (16 x 64, storage type) is read coalesced -- 4 rows x 256 bytes per load -- and parked in a
+//     wave-private LDS tile; a lane (row i = l&15, group g = l>>4) then picks its A values as 4 vectors
+//     xs[i][16m + 4g .. +3]: MFMA number (m, e) contracts the four columns {16m + 4g + e}, g = 0..3 -- any order
+//     of the columns is as good as another for a sum, and this one costs no lane movement;
+//   * the T tile (64 columns x 16 NT topics) is shared by the 4 waves through LDS, stored [column][topic] (stride
+//     16 NT + 1: the transposing stores hit different banks), so the B fragment of (m, e), topic tile c is 16
+//     consecutive doubles; double-buffered: the next tile's loads are in flight during the MFMAs.
+// Result layout (f64 MFMA): lane l, register r = X row (l>>4) + 4r, topic 16c + (l&15).
+// =========================================================================================
+template <typename SX, int NT>
+__global__ __launch_bounds__(256) void k_xtt_mfma(const SX* __restrict__ X, i64 ldx, const double* __restrict__ T,
+                                                  i64 ldt, int n, int d, int m, double* __restrict__ Qt, i64 ldq) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;                 // elements per 16-byte vector: 4 (fp32) or 2 (fp64)
+    constexpr int TS = 16 * NT + 1;           // row stride of the T tile [column][topic]
+    constexpr int XS = 64 + VN;               // row stride of the X tile (elements)
+    constexpr int NI = (16 * NT) / 4;         // T rows per thread and tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tsh = reinterpret_cast<double*>(smem);                         // [2][64][TS]
+    SX* xsh = reinterpret_cast<SX*>(tsh + 2 * 64 * TS);                    // [4 waves][16][XS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 row0 = (i64)blockIdx.x * 64 + wave * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    SX* xs = xsh + (size_t)wave * 16 * XS;
+    const int tc = tid & 63, tr = tid >> 6;
+    double stage[NI];
+    auto fetch = [&](i64 c0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int l = tr + 4 * i;
+            stage[i] = (l < m && c0 + tc < d) ? T[(i64)l * ldt + c0 + tc] : 0.0;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) tsh[((size_t)buf * 64 + tc) * TS + tr + 4 * i] = stage[i];
+    };
+    // X tile: VN-element vectors, 64 / VN per row, 64 lanes cover (64 * VN / 64) = VN rows per load
+    constexpr int VPR = 64 / VN, RPL = 64 / VPR, NL = 16 / RPL;
+    V xv[NL];
+    auto fetch_x = [&](i64 c0) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int r = q * RPL + lane / VPR, cv = lane % VPR;
+            const i64 i = row0 + r, j = c0 + (i64)cv * VN;
+            if (i < n && j + VN - 1 < d) {
+                xv[q] = __builtin_nontemporal_load(reinterpret_cast<const V*>(X + i * ldx + j));
+            } else {
+                double e[VN];
+#pragma unroll
+                for (int c = 0; c < VN; ++c) e[c] = (i < n && j + c < d) ? (double)X[i * ldx + j + c] : 0.0;
+                xv[q] = XV::pack(e);
+            }
+        }
+    };
+    auto park_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int r = q * RPL + lane / VPR, cv = lane % VPR;
+            *reinterpret_cast<V*>(xs + r * XS + cv * VN) = xv[q];
+        }
+    };
+    f64x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    fetch_x(0);
+    park(0);
+    park_x();
+    __syncthreads();
+    int buf = 0;
+    for (i64 c0 = 0; c0 < d; c0 += 64, buf ^= 1) {
+        const bool more = c0 + 64 < d;
+        if (more) { fetch(c0 + 64); fetch_x(c0 + 64); }
+        const double* tb = tsh + (size_t)buf * 64 * TS;
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            double a4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a4[e] = (double)xs[li * XS + 16 * mm + 4 * lg + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double* brow = tb + (size_t)(16 * mm + 4 * lg + e) * TS + li;
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[e], brow[16 * c], acc[c], 0, 0, 0);
+            }
+        }
+        __syncthreads();              // every wave is done with this step's tiles (its own X tile included)
+        if (more) { park(buf ^ 1); park_x(); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int l = 16 * c + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const i64 i = row0 + lg + 4 * r;
+            if (l < m && i < n) Qt[(i64)l * ldq + i] = acc[c][r];
+        }
+    }
+}
+
 // partial sums of v, v^2 and |v| over a strided matrix: out[b] = {sum, sumsq, sumabs}
 __global__ __launch_bounds__(256) void k_norms(const double* __restrict__ A, i64 rows, i64 cols, i64 ld,
                                                double* __restrict__ out) {

@@ -1086,7 +1086,9 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (c->sparse) {
         // no dense pass: the row copy is cut into column blocks (= Ypart panels), the column copy into row blocks
         // (= Zpart rows); block widths so that three factor tables of a block fit SP_BLOCK_BYTES of LDS
-        const i64 cap = SP_BLOCK_BYTES / (3 * (dtype == RRI_F32 ? 4 : 8));
+        i64 block_bytes = SP_BLOCK_BYTES;
+        if (const char* e = getenv("RRI_SP_BLOCK_KB")) block_bytes = std::min<i64>(SP_BLOCK_BYTES, std::max(8, atoi(e)) * 1024LL);
+        const i64 cap = block_bytes / (3 * (dtype == RRI_F32 ? 4 : 8));
         for (int w = 0; w < 2; ++w) {
             rri_ctx::SpCopy& cp = c->sp[w];
             cp.gdim = w == 0 ? d : n;

@@ -39,6 +39,14 @@ def test_library_exports_every_declared_symbol():
     assert typed.rri_abi_version() == _capi.ABI_VERSION
 
 
+def test_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C99 on its own (no C++ or HIP types leak into it)"""
+    import subprocess
+    r = subprocess.run(['gcc', '-x', 'c', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only',
+                        os.path.join(ROOT, 'include', 'rri_hip.h')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_abi_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.Params) == 8 * 4 + 7 * 8
     assert ctypes.sizeof(_capi.Event) == 16

@@ -415,3 +415,21 @@ def test_captured_sweeps_equal_eager_sweeps(weighted, monkeypatch):
         if mode == '2':
             ref = out['0', key]
             assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]) and v[2] == ref[2] and v[3] == ref[3], key
+
+
+@pytest.mark.gpu
+def test_the_abi_from_plain_c(tmp_path):
+    """tests/c/abi_smoke.c: the boundary used by a C program with no Python or torch in the process (gcc, -lrri_hip)"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from rri_nmf_amd import _capi
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    exe = str(tmp_path / 'abi_smoke')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'c', 'abi_smoke.c'), '-o', exe, '-L', libdir, '-lrri_hip', '-lm',
+                    '-Wl,-rpath,' + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    tag, o0, o1, cw, ct = r.stdout.split()
+    assert tag == 'ok' and float(o1) < 0.2 * float(o0) and float(cw) > 0 and float(ct) > 0

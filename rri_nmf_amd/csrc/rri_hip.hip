@@ -244,6 +244,8 @@ int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for 
 int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
                         // launch-bound sizes, 2 always
 int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
+int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
+                             // interleaved up to 1024 workgroups (+2 % at 20000 x 5000; -1 % at C3, where it stays off)
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
@@ -259,7 +261,8 @@ struct LaunchX {
         typedef typename std::conditional<UPD, SX, const SX>::type XT;
         hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
                            pass_shmem(c, UPD), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
-                           c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st, job);
+                           c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st, job,
+                           (g_pass_interleave == 1 || (g_pass_interleave < 0 && c->npanels * c->nrb <= 1024)) ? c->nrb : 0);
     }
     template <bool DO_Y, bool DO_Z, bool UPD>
     static void pass_cfg(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a,
@@ -1037,6 +1040,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
+    if (const char* e = getenv("RRI_PASS_IL")) g_pass_interleave = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_TROW_SMALL")) g_trow_small = atoi(e) != 0;
     if (const char* e = getenv("RRI_GRAPH")) g_graph = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;

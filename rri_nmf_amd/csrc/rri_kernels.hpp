@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
                                               double* __restrict__ Ypart, double* __restrict__ Zpart, i64 ldz,
                                               int rpb, int npg, const double* __restrict__ avec,
                                               const double* __restrict__ bvec, const DevState* __restrict__ st,
-                                              const TgramJob job) {
+                                              const TgramJob job, int nrb_il) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
@@ -173,13 +173,19 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
     double* tile = wsh + (UPD ? 2 : 1) * rpb + wave * (8 * 72);   // [4][8*72] private row-sum tiles (RS)
     const int pg = bid % npg;
     const int rb = bid / npg;
-    const int row0 = rb * rpb;
-    const int row1 = min(n, row0 + rpb);
+    // Rows of this block, local index li = q U + u  ->  global row.  Interleaved (nrb_il > 0): chunk q of U rows is
+    // chunk number q nrb + rb of the matrix, so the blocks that run at one time walk ONE contiguous window of X, as a
+    // linear stream does (worth 2 % at 20000 x 5000, nothing at C3: the host picks).  Contiguous (nrb_il == 0): rows
+    // rb rpb .. rb rpb + rpb - 1.
+    auto grow = [&](int li) -> int {
+        return nrb_il > 0 ? ((li / U) * nrb_il + rb) * U + (li % U) : rb * rpb + li;
+    };
     const int col = (pg * 4 + wave) * PW + lane * VN;
     if (DO_Z || UPD) {
-        for (int i = threadIdx.x; i < row1 - row0; i += 256) {
-            if (DO_Z) wsh[i] = wcol[row0 + i];
-            if (UPD) ash[i] = avec[row0 + i];
+        for (int i = threadIdx.x; i < rpb; i += 256) {
+            const int g = grow(i);
+            if (DO_Z) wsh[i] = g < n ? wcol[g] : 0.0;
+            if (UPD) ash[i] = g < n ? avec[g] : 0.0;
         }
         __syncthreads();
     }
@@ -193,28 +199,30 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
         bv[e] = (UPD && ok) ? bvec[col + e] : 0.0;
     }
     if (wave_has_cols) {
-        for (int r = row0; r < row1; r += U) {
+        for (int l0 = 0; l0 < rpb; l0 += U) {
+            const int r = grow(l0);                  // the U rows of a chunk are consecutive
+            if (r >= n) break;                       // later chunks lie further down still
             V x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rr = r + u;
                 x[u] = XV::zero();
-                if (rr < row1 && ok) x[u] = stream_load<NT>(reinterpret_cast<const V*>(X + (i64)rr * ldx + col));
+                if (rr < n && ok) x[u] = stream_load<NT>(reinterpret_cast<const V*>(X + (i64)rr * ldx + col));
             }
             double ys[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rr = r + u;
                 double wv = 0.0, na = 0.0;
-                if (DO_Z && rr < row1) wv = wsh[rr - row0];
-                if (UPD && rr < row1) na = -ash[rr - row0];
+                if (DO_Z && rr < n) wv = wsh[l0 + u];
+                if (UPD && rr < n) na = -ash[l0 + u];
                 double xe[VN];
                 XV::unpack(x[u], xe);
                 if constexpr (UPD) {
 #pragma unroll
                     for (int e = 0; e < VN; ++e) xe[e] = fma(na, bv[e], xe[e]);
                     const V rounded = XV::pack(xe);
-                    if (rr < row1 && ok) stream_store<NT>(reinterpret_cast<V*>(X + (i64)rr * ldx + col), rounded);
+                    if (rr < n && ok) stream_store<NT>(reinterpret_cast<V*>(X + (i64)rr * ldx + col), rounded);
                     // the stored residual is what later passes read: continue with the ROUNDED values
                     if constexpr (sizeof(SX) == 4) XV::unpack(rounded, xe);
                 }
@@ -228,15 +236,13 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
             }
             if constexpr (DO_Y && RS) {
                 const double tot = wave_rowsum8(reinterpret_cast<const double (&)[8]>(ys), tile, lane);
-                const int rr = r + (lane >> 3);
-                if ((lane & 7) == 0 && rr < row1) ysh[wave * rpb + rr - row0] = tot;
+                if ((lane & 7) == 0) ysh[wave * rpb + l0 + (lane >> 3)] = tot;
             } else if (DO_Y) {
                 double yv = ys[0];
 #pragma unroll
                 for (int u = 1; u < U; ++u)
                     if (lane == u) yv = ys[u];
-                const int rr = r + lane;
-                if (lane < U && rr < row1) ysh[wave * rpb + rr - row0] = yv;
+                if (lane < U) ysh[wave * rpb + l0 + lane] = yv;
             }
         }
         if (DO_Z && ok) {
@@ -244,12 +250,14 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
             for (int e = 0; e < VN; ++e) Zpart[(i64)rb * ldz + col + e] = zacc[e];
         }
     } else if (DO_Y) {
-        for (int i = lane; i < row1 - row0; i += 64) ysh[wave * rpb + i] = 0.0;
+        for (int i = lane; i < rpb; i += 64) ysh[wave * rpb + i] = 0.0;
     }
     if (DO_Y) {
         __syncthreads();
-        for (int i = threadIdx.x; i < row1 - row0; i += 256)
-            Ypart[(i64)pg * n + row0 + i] = (ysh[i] + ysh[rpb + i]) + (ysh[2 * rpb + i] + ysh[3 * rpb + i]);
+        for (int i = threadIdx.x; i < rpb; i += 256) {
+            const int g = grow(i);
+            if (g < n) Ypart[(i64)pg * n + g] = (ysh[i] + ysh[rpb + i]) + (ysh[2 * rpb + i] + ysh[3 * rpb + i]);
+        }
     }
 }
 

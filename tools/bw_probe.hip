@@ -156,6 +156,36 @@ __global__ __launch_bounds__(256) void rmw_panel(float* __restrict__ X, i64 ldx,
     }
 }
 
+// the pass pattern with INTERLEAVED row chunks: block rb takes the chunks of U rows number rb, rb + nrb, rb + 2 nrb, ...
+// so that the blocks running at one time cover one contiguous window of the matrix (as a linear stream does)
+template <int U, bool NT, bool WRITE>
+__global__ __launch_bounds__(256) void rmw_panel_il(float* __restrict__ X, i64 ldx, int n, int nrb, int npg, float c, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const i64 col = (i64)(pg * 4 + wave) * 256 + lane * 4;
+    if (col >= ldx) return;
+    float acc = 0.f;
+    for (int r = rb * U; r < n; r += nrb * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4* xp = (float4*)(X + (i64)(r + u) * ldx + col);
+            v[u] = (r + u < n) ? (NT ? __builtin_nontemporal_load(xp) : *xp) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4* xp = (float4*)(X + (i64)(r + u) * ldx + col);
+            if (WRITE) {
+                v[u] = v[u] - c;
+                if (r + u < n) { if (NT) __builtin_nontemporal_store(v[u], xp); else *xp = v[u]; }
+            } else {
+                acc += v[u].x + v[u].y + v[u].z + v[u].w;
+            }
+        }
+    }
+    if (!WRITE && acc == 123.456f) out[0] = acc;
+}
+
 template <typename F>
 double timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -229,6 +259,16 @@ int main(int argc, char** argv) {
             snprintf(nm, 96, "rmw_panel U8 wgs~%d", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<8, false>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
             snprintf(nm, 96, "rmw_panel U4 NT wgs~%d", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<4, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
             snprintf(nm, 96, "rmw_panel U16 NT wgs~%d", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel<16, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, rpb, npg, 1.0f));
+        }
+    }
+    {
+        const int npg = (d + 1023) / 1024;
+        for (int wgs : {1024, 2048, 4096}) {
+            const int nrb = wgs / npg;
+            char nm[96];
+            snprintf(nm, 96, "rmw_panel_il U8 NT wgs~%d (r+w bytes)", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel_il<8, true, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, nrb, npg, 1.0f, out));
+            snprintf(nm, 96, "rmw_panel_il U4 NT wgs~%d (r+w bytes)", wgs); RUN(nm, 2 * elems * 4.0, hipLaunchKernelGGL((rmw_panel_il<4, true, true>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, nrb, npg, 1.0f, out));
+            snprintf(nm, 96, "rd_panel_il U8 NT wgs~%d (read only)", wgs); RUN(nm, elems * 4.0, hipLaunchKernelGGL((rmw_panel_il<8, true, false>), dim3(nrb * npg), dim3(256), 0, 0, Y, (i64)d, n, nrb, npg, 1.0f, out));
         }
     }
     return 0;

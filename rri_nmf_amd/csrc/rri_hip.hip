@@ -239,7 +239,6 @@ struct TimedScope {
 // geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
 int g_pass_unroll = 8, g_pass_nt = 1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8)
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
-int g_resid_waves = 4;  // RRI_RESID_WAVES=8: 128-row instead of 64-row workgroups in k_resid_mfma (measured: no faster)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
 int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
                         // launch-bound sizes, 2 always
@@ -435,13 +434,6 @@ struct LaunchX {
                            c->ldx, Tm, c->LD, (int)c->n, (int)c->d, m, out, c->ldw);
     }
     static void xtt(rri_ctx* c) { xtt_any(c, c->T, c->k, c->Qt); }
-    // column sums of X against an arbitrary n-vector (device): leaves them in red[0..LD)
-    static void colsums(rri_ctx* c, const double* wvec) {
-        pass_cfg<false, true, false>(c, c->X, c->T, wvec, nullptr, nullptr);
-        const int nb = (int)((c->LD + 31) / 32);
-        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
-                           (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
-    }
     // column sums against NV = 8 row-vectors at once (Qt: 8 x n, stride ldw): out rows <- X^T q_v
     static void colsums8(rri_ctx* c, const double* Qt, int nv, double* zmulti, double* out_rows) {
         constexpr int NV = 8;
@@ -466,18 +458,9 @@ struct LaunchX {
             const int ks = c->k <= 16 ? 4 : c->k <= 32 ? 8 : c->k <= 48 ? 12 : c->k <= 52 ? 13 : 16;
             const size_t shm = 2 * (size_t)(4 * ks) * 64 * sizeof(double);
 #define RRI_RESID_M(MK, WE, KS_)                                                                                     \
-    do {                                                                                                             \
-        if (g_resid_waves == 8)                                                                                      \
-            hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 8>), dim3((unsigned)((c->n + 127) / 128)), dim3(512), shm, \
-                               c->stream, (const SX*)c->X, c->ldx, (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, \
-                               c->ldb, (const double*)c->W, c->ldw, (const double*)c->T, c->LD, (int)c->n, (int)c->d,  \
-                               c->k, rowobj, rowpos, (SX*)c->E, c->LD);                                              \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, \
-                               c->ldx, (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, \
-                               c->ldw, (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos,        \
-                               (SX*)c->E, c->LD);                                                                    \
-    } while (0)
+    hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
+                       (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,      \
+                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
 #define RRI_RESID_K(MK, WE)                          \
     switch (ks) {                                    \
         case 4: RRI_RESID_M(MK, WE, 4); break;       \
@@ -1044,7 +1027,6 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_TROW_SMALL")) g_trow_small = atoi(e) != 0;
     if (const char* e = getenv("RRI_GRAPH")) g_graph = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
-    if (const char* e = getenv("RRI_RESID_WAVES")) g_resid_waves = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);

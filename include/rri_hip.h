@@ -171,6 +171,15 @@ rri_status rri_rollback(rri_ctx* ctx);
 rri_status rri_X_times(rri_ctx* ctx, const double* B, int32_t m, double* out);
 rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 
+/* Preprocessing of the resident dense X in place (unweighted handles):
+ *   rri_column_positive_counts  df[j] = #{i : X[i,j] > 0}, the document frequencies of tfidf (matrixops.py:169)
+ *   rri_scale_X                 X[i,j] <- (X[i,j] * col_scale[j]) / (sum_j X[i,j] * col_scale[j] + spacing(1)) when
+ *                               normalize_rows != 0 (rows summing to < 1e-10 become 1/d: normalize, matrixops.py:139-147),
+ *                               else X[i,j] * col_scale[j] (X * idf, matrixops.py:172); col_scale == NULL: all ones.
+ * float64 arithmetic, rounded to the handle's storage type when stored. */
+rri_status rri_column_positive_counts(rri_ctx* ctx, double* df_out);
+rri_status rri_scale_X(rri_ctx* ctx, const double* col_scale, int32_t normalize_rows);
+
 /* ---- row-sharded multi-GPU (one process per GPU; the caller owns the collective) ---- */
 /* A topic step splits at the one cross-row reduction it needs.  rri_topic_reduce_local
  * leaves this rank's partial sums [w_t^T X (LD) | RRI_GRAM_SLICES x (w_t^T W (k), ||w_t||^2, sum W[:,t-1])]

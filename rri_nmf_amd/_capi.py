@@ -71,6 +71,8 @@ PROTOTYPES = {
     'rri_rollback': (_I32, [_P]),
     'rri_X_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
     'rri_Xt_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
+    'rri_column_positive_counts': (_I32, [_P, C.POINTER(_D)]),
+    'rri_scale_X': (_I32, [_P, C.POINTER(_D), _I32]),
     'rri_reduce_buffer': (_I32, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     'rri_bind_reduce_buffer': (_I32, [_P, _P, _I64]),
     'rri_reduce_read': (_I32, [_P, C.POINTER(C.c_double), _I64]),

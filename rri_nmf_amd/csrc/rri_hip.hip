@@ -1966,6 +1966,66 @@ rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
     return to_host(c, outm.p, c->LD, out, m, RRI_F64, c->d, m, RRI_F64, true);
 }
 
+// ---- preprocessing of the resident X ---------------------------------------------------------------------------
+rri_status rri_column_positive_counts(rri_ctx* c, double* df_out) {
+    CHECK_CTX(c);
+    if (!df_out) return fail(c, RRI_ERR_INVALID, "df_out is NULL");
+    if (c->weighted || !c->have_X) return fail(c, RRI_ERR_INVALID, "needs an unweighted handle with a dense X");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+    HIPCHK(c, hipMemsetAsync(c->Zpart, 0, (size_t)c->nrb * c->LD * sizeof(double), c->stream));
+    DISPATCH(c, hipLaunchKernelGGL((k_col_count<typename L::Elem>), dim3(c->npanels * c->nrb), dim3(256), 0, c->stream,
+                                   (const typename L::Elem*)c->X, c->ldx, (int)c->n, ncols, c->Zpart, c->LD, c->rpb,
+                                   c->npanels));
+    LK::reduce(c);
+    HIPCHK(c, hipMemcpyAsync(df_out, c->red, (size_t)c->d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    invalidate(c);   // Zpart / red were used as scratch
+    return RRI_OK;
+}
+
+rri_status rri_scale_X(rri_ctx* c, const double* col_scale, int32_t normalize_rows) {
+    CHECK_CTX(c);
+    if (c->weighted || !c->have_X) return fail(c, RRI_ERR_INVALID, "needs an unweighted handle with a dense X");
+    if (!c->own_X) return fail(c, RRI_ERR_INVALID, "X is bound caller memory: it is not rewritten in place");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    DevTmp sd, inv;
+    double* sdev = nullptr;
+    HIPCHK(c, sd.alloc((size_t)c->LD * sizeof(double)));
+    sdev = (double*)sd.p;
+    if (col_scale) {
+        HIPCHK(c, hipMemsetAsync(sdev, 0, (size_t)c->LD * sizeof(double), c->stream));
+        HIPCHK(c, hipMemcpyAsync(sdev, col_scale, (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+        std::vector<double> ones((size_t)c->LD, 0.0);
+        std::fill(ones.begin(), ones.begin() + c->d, 1.0);
+        HIPCHK(c, hipMemcpyAsync(sdev, ones.data(), (size_t)c->LD * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    double* invdev = nullptr;
+    if (normalize_rows) {
+        HIPCHK(c, inv.alloc((size_t)c->n * sizeof(double)));
+        invdev = (double*)inv.p;
+        // row sums of X * col_scale = the row dots of the streaming pass against col_scale
+        const int tsave = c->timing;
+        c->timing = 0;
+        DISPATCH(c, (L::template pass_cfg<true, false, false>(c, c->X, sdev, c->W, nullptr, nullptr)));
+        c->timing = tsave;
+        hipLaunchKernelGGL(k_row_inverse, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)c->Ypart, c->npanels, (int)c->n, invdev);
+    }
+    DISPATCH(c, hipLaunchKernelGGL((k_scale2d<typename L::Elem>), dim3(8192), dim3(256), 0, c->stream,
+                                   (typename L::Elem*)c->X, c->ldx, c->n, (int)c->d, col_scale ? (const double*)sdev : nullptr,
+                                   (const double*)invdev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    invalidate(c);
+    c->q_valid = false;
+    c->x_sq_valid = false;
+    return RRI_OK;
+}
+
 // ---- row-sharded multi-GPU ---------------------------------------------------------------------------------
 rri_status rri_reduce_buffer(rri_ctx* c, void** dev_ptr, int64_t* n_elems) {
     CHECK_CTX(c);

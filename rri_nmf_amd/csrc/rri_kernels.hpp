@@ -322,6 +322,80 @@ __global__ __launch_bounds__(256) void k_colsums(const SX* __restrict__ X, i64 l
 }
 
 // =========================================================================================
+// Preprocessing of the resident X (matrixops.py:124-179: tf-idf and row normalisation), SURVEY 8f rank 3.
+//   k_col_count  df_j = #{i : X_ij > 0}, geometry of k_colsums (partials per row block, k_reduce adds them)
+//   k_row_inverse  xs_i = sum of the row-dot panels + spacing(1); inv_i = 1 / xs_i; rows with xs_i < 1e-10 are flagged
+//                  (inv_i = -1): they become uniform 1/d (normalize's zero_sum_fix)
+//   k_scale2d    X_ij <- (X_ij * s_j) * inv_i in place, one linear stream (the fastest read-modify-write pattern)
+// =========================================================================================
+template <typename SX>
+__global__ __launch_bounds__(256) void k_col_count(const SX* __restrict__ X, i64 ldx, int n, int ncols,
+                                                   double* __restrict__ Zpart, i64 ldz, int rpb, int npg) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;
+    constexpr int PW = 64 * VN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const int row0 = rb * rpb, row1 = min(n, row0 + rpb);
+    const int col = (pg * 4 + wave) * PW + lane * VN;
+    if (col >= ncols) return;
+    double acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = 0.0;
+    for (int r = row0; r < row1; r += 4) {
+        V x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            x[u] = (r + u < row1) ? stream_load<true>(reinterpret_cast<const V*>(X + (i64)(r + u) * ldx + col)) : XV::zero();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double xe[VN];
+            XV::unpack(x[u], xe);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] += xe[e] > 0.0 ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) Zpart[(i64)rb * ldz + col + e] = acc[e];
+}
+
+__global__ __launch_bounds__(256) void k_row_inverse(const double* __restrict__ Ypart, int npanels, int n,
+                                                     double* __restrict__ inv) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double xs = 0.0;
+    for (int q = 0; q < npanels; ++q) xs += Ypart[(i64)q * n + i];
+    xs += 2.220446049250313e-16;                      // np.spacing(1), matrixops.py:140
+    inv[i] = xs < 1e-10 ? -1.0 : 1.0 / xs;
+}
+
+template <typename SX>
+__global__ __launch_bounds__(256) void k_scale2d(SX* __restrict__ X, i64 ldx, i64 n, int d, const double* __restrict__ s,
+                                                 const double* __restrict__ inv) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;
+    const i64 vpr = ldx / VN, total = n * vpr;         // ldx is a multiple of the vector width
+    const double uniform = 1.0 / (double)d;
+    for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < total; v += (i64)gridDim.x * 256) {
+        const i64 i = v / vpr;
+        const int j = (int)(v - i * vpr) * VN;
+        V* p = reinterpret_cast<V*>(X + i * ldx + j);
+        double xe[VN];
+        XV::unpack(__builtin_nontemporal_load(p), xe);
+        const double r = inv ? inv[i] : 1.0;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            if (j + e >= d) { xe[e] = 0.0; continue; }                       // pad columns stay zero
+            const double t = s ? xe[e] * s[j + e] : xe[e];                    // X * idf               (:172)
+            xe[e] = r < 0.0 ? uniform : r * t;                                // d * X, or the zero-sum fix (:143-147)
+        }
+        __builtin_nontemporal_store(XV::pack(xe), p);
+    }
+}
+
+// =========================================================================================
 // W is stored k-major on the device (Wt: k x ldw, ldw >= n): column t of W is the contiguous
 // row Wt[t,:], so the pass reads the active column coalesced and k_wcol needs no LDS staging.
 //

@@ -318,6 +318,36 @@ class RRIEngine(object):
                                            out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    # ---- preprocessing of the resident X (matrixops.py:124-179) ---------------------------
+    def column_positive_counts(self):
+        """df[j] = #{i: X[i, j] > 0}"""
+        out = np.empty(self.d, dtype=np.float64)
+        self._check(self._lib.rri_column_positive_counts(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def scale_X(self, col_scale=None, normalize_rows=False):
+        """X <- X * col_scale (per column), then rows divided by their sums when normalize_rows (in place)"""
+        ptr = None
+        if col_scale is not None:
+            col_scale = np.ascontiguousarray(col_scale, dtype=np.float64).ravel()
+            if col_scale.size != self.d:
+                raise ValueError('col_scale must have d entries')
+            ptr = col_scale.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self._lib.rri_scale_X(self._h, ptr, int(bool(normalize_rows))))
+
+    def preprocess(self, tfidf=False, normalize=False):
+        """tf-idf and/or row normalisation of the resident X, as matrixops.tfidf / normalize produce them.
+        tfidf: True (idf from this X), an idf vector (transform of new documents), or False.  Returns the idf used."""
+        idf = None
+        if tfidf is True:
+            df = self.column_positive_counts()
+            idf = np.log(self.n / (df + np.spacing(1)))       # matrixops.py:169-170
+        elif tfidf is not False and tfidf is not None:
+            idf = np.asarray(tfidf, dtype=np.float64).ravel()
+        if idf is not None or normalize:
+            self.scale_X(idf, normalize)
+        return idf
+
     # ---- row-sharded stepping -----------------------------------------------------------
     def reduce_buffer(self):
         ptr, cnt = C.c_void_p(), C.c_int64()

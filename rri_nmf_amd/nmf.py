@@ -44,20 +44,23 @@ class TrueObjComputer(object):
     objective value; true_objective() re-evaluates it on the device."""
 
     def __init__(self, X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, Wm, wr, dtype=None, device=0,
-                 sparse_pattern=None):
+                 sparse_pattern=None, preprocess=None):
         self.X, self.W, self.T = X, W, T
         self.reg_w_l2, self.reg_t_l2 = reg_w_l2, reg_t_l2
         self.reg_w_l1, self.reg_t_l1 = reg_w_l1, reg_t_l1
         self.Wm, self.wr = Wm, wr
         self.obj = np.inf
         self._dtype, self._device, self._sparse_pattern = dtype, device, sparse_pattern
+        self._preprocess = preprocess      # device-side tf-idf / normalisation that nmf() applied to X (idf resolved)
 
     def true_objective(self):
         X = self.X   # row weights, when used, are already folded into X by nmf() (nmf.py:335-338)
         n, d = X.shape
         k = self.W.shape[1]
-        with _engine_with_problem(X, self.Wm, k, _storage_dtype(X, self._dtype), self._device,
-                                  self._sparse_pattern) as eng:
+        sdt = _storage_dtype(X, self._dtype) if self._preprocess is None else np.dtype(self._dtype or np.float64)
+        with _engine_with_problem(X, self.Wm, k, sdt, self._device, self._sparse_pattern) as eng:
+            if self._preprocess is not None:
+                eng.preprocess(**self._preprocess)
             eng.set_W(self.W)
             eng.set_T(self.T)
             eng.set_params(reg_w_l1=self.reg_w_l1, reg_w_l2=self.reg_w_l2, reg_t_l1=self.reg_t_l1,
@@ -162,6 +165,74 @@ def _is_empty(a):
     return int(np.prod(np.shape(a))) == 0
 
 
+class _ResidentX(object):
+    """What the initialisers need of an X that exists only on the device (after device-side preprocessing):
+    its shape and its mean; the products with it go through the engine."""
+
+    def __init__(self, engine):
+        self.shape = (engine.n, engine.d)
+        self._engine = engine
+        self._mean = None
+
+    def mean(self):
+        if self._mean is None:
+            rows = self._engine.X_times(np.ones((self.shape[1], 1)))
+            self._mean = float(rows.sum()) / (float(self.shape[0]) * self.shape[1])
+        return self._mean
+
+
+def _preprocess_spec(preprocess):
+    """(tfidf, normalize) of the `preprocess` option: None, a dict {'tfidf': True | idf vector | False,
+    'normalize': bool}, or a string / sequence naming the steps ('tfidf', 'normalize')"""
+    if preprocess is None:
+        return None
+    if isinstance(preprocess, str):
+        preprocess = (preprocess,)
+    if isinstance(preprocess, dict):
+        unknown = set(preprocess) - {'tfidf', 'normalize'}
+        if unknown:
+            raise ValueError('unknown preprocessing step(s): %s' % sorted(unknown))
+        tfidf_opt, norm_opt = preprocess.get('tfidf', False), bool(preprocess.get('normalize', False))
+    else:
+        steps = list(preprocess)
+        unknown = set(steps) - {'tfidf', 'normalize'}
+        if unknown:
+            raise ValueError('unknown preprocessing step(s): %s' % sorted(unknown))
+        tfidf_opt, norm_opt = 'tfidf' in steps, 'normalize' in steps
+    if tfidf_opt is None:
+        tfidf_opt = False
+    if tfidf_opt is False and not norm_opt:
+        return None
+    return tfidf_opt, norm_opt
+
+
+def _preprocess_on_host(X, tfidf_opt, norm_opt):
+    """matrixops.tfidf / normalize on the host: the route when something (callbacks, weights, sparse input)
+    needs the preprocessed X in host memory"""
+    from .matrixops import tfidf as host_tfidf
+    idf = None
+    if tfidf_opt is True:
+        X, idf = host_tfidf(X, return_idf=True)
+        if scipy.sparse.issparse(X):
+            X = X.tocsr()
+        idf = np.asarray(idf.todense() if scipy.sparse.issparse(idf) else idf, dtype=np.float64).ravel()
+    elif tfidf_opt is not False:
+        idf = np.asarray(tfidf_opt, dtype=np.float64).ravel()
+        X = X.multiply(idf).tocsr() if scipy.sparse.issparse(X) else X * idf
+    if norm_opt and scipy.sparse.issparse(X):     # matrixops.normalize is written for dense arrays: same arithmetic on CSR
+        tot = np.asarray(X.sum(1)).ravel() + np.spacing(1)
+        X = (scipy.sparse.diags(1.0 / tot) @ X).tocsr()
+        empty = np.nonzero(tot < 1e-10)[0]
+        if empty.size:
+            X = X.tolil()
+            for i in empty:
+                X[i, :] = 1.0 / X.shape[1]
+            X = X.tocsr()
+    elif norm_opt:
+        X = normalize(X)
+    return X, idf
+
+
 DEVICE_INIT_MIN_ELEMS = 2e7   # from this many entries of X on, the SVD behind NNDSVD uses the device products
 
 
@@ -220,11 +291,16 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0,
         diagnostics=[], store_gradients=False,
         ind_rows_to_store=None, eps_gauss_t=None, delta_gauss_t=None,
-        *, dtype=None, device=0, device_init=None, sparse_pattern=None):
+        *, dtype=None, device=0, device_init=None, sparse_pattern=None, preprocess=None):
     """Non-negative factorisation X ~ W T by rank-one residue iteration; see the module docstring and
     the reference's docstring (nmf.py:109-269) for the parameters.  Returns a dict with 'W', 'T',
     'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
-    is tracked, 'obj_history' and 'obj_calculator'; 'diagnostics' when callbacks are given."""
+    is tracked, 'obj_history' and 'obj_calculator'; 'diagnostics' when callbacks are given.
+
+    preprocess (keyword only, not in the reference's signature): tf-idf and / or row normalisation of X
+    (matrixops.py:124-179) before the factorisation -- {'tfidf': True | idf vector | False, 'normalize': bool} or
+    the step names.  A dense X without weights or host callbacks is uploaded raw and rewritten in place on the
+    device; every other case preprocesses on the host.  The idf used comes back as rtv['idf']."""
     if store_gradients or ind_rows_to_store is not None:
         # the reference cannot return from such a call: nmf.py:543 hands stack_matrices its reshape lambda as
         # `dict_key`, which indexes an ndarray with it (IndexError) -- there is no behaviour to reproduce
@@ -248,6 +324,14 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         X = np.asarray(X)
     W_mat = _sparse_mask_or_dense(W_mat)
     rtv = {}
+    spec = _preprocess_spec(preprocess)
+    device_spec = None
+    if spec is not None:
+        host_callbacks = bool(diagnostics) or (callable(early_stop) and getattr(early_stop, 'device_entries', None) is None)
+        if scipy.sparse.issparse(X) or W_mat is not None or w_row is not None or host_callbacks:
+            X, rtv['idf'] = _preprocess_on_host(X, *spec)
+        else:
+            device_spec = {'tfidf': spec[0], 'normalize': spec[1]}
     n, d = X.shape
 
     # ---- option sanity, exactly as nmf.py:280-315 ---------------------------------------------
@@ -293,7 +377,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if logger.level <= logging.DEBUG:           # nmf.py:366-367 (see the note at the logger)
         compute_obj_each_iter = True
 
-    sdt = _storage_dtype(X, dtype)
+    # host preprocessing yields float64 whatever X was (X * idf promotes): the device route stores the same by default
+    sdt = _storage_dtype(X, dtype) if device_spec is None else np.dtype(dtype or np.float64)
     needs_init = _is_empty(W_in) or _is_empty(T_in)
     if not _is_empty(W_in) and np.shape(W_in) != (n, k):       # shape errors before any device work (nmf.py:853-860)
         raise ValueError('W_in has wrong dimensions, must be n*k')
@@ -302,7 +387,14 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern)
     try:
         on_device = device_init if device_init is not None else (float(n) * d >= DEVICE_INIT_MIN_ELEMS)
-        W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X, k=k, init=init,
+        X_init = X
+        if device_spec is not None:
+            idf = eng.preprocess(**device_spec)
+            rtv['idf'] = idf
+            device_spec = {'tfidf': idf if idf is not None else False, 'normalize': device_spec['normalize']}
+            on_device = True                 # the preprocessed X exists only on the device
+            X_init = _ResidentX(eng)
+        W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X_init, k=k, init=init,
                                         random_state=random_state, project_T_each_iter=project_T_each_iter,
                                         project_W_each_iter=project_W_each_iter, w_row_sum=w_row_sum,
                                         t_row_sum=t_row_sum, fix_W=fix_W, fix_T=fix_T, n=n, d=d,
@@ -395,7 +487,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if compute_obj_each_iter:
         rtv['obj_history'] = obj_history
         calc = TrueObjComputer(X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, W_mat, w_row,
-                               dtype=dtype, device=device, sparse_pattern=sparse_pattern)
+                               dtype=dtype, device=device, sparse_pattern=sparse_pattern, preprocess=device_spec)
         calc.obj = obj_history[-1] if obj_history else np.inf
         rtv['obj_calculator'] = calc
     rtv['iter_cputime'] = iter_cputime

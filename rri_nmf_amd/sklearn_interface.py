@@ -187,21 +187,24 @@ class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.Tra
         self.nmf_kwargs = nmf_kwargs
         self.do_final_project_W = do_final_project_W
 
-    def _prepare_fit(self, X):
-        if self.handle_tfidf:
-            X, self.idf = tfidf(X, return_idf=True)
-        if self.handle_normalization:
-            X = normalize(X)
-        return X
+    def _preprocess_kwargs(self, idf=None):
+        """handle_tfidf / handle_normalization as nmf()'s `preprocess` option (sklearn_interface.py:243-247, 303-306):
+        a dense X is then rewritten on the device after the upload instead of on the host before it"""
+        if not (self.handle_tfidf or self.handle_normalization):
+            return {}
+        tf = False if not self.handle_tfidf else (True if idf is None else idf)
+        return {'preprocess': {'tfidf': tf, 'normalize': bool(self.handle_normalization)}}
 
     def _solve(self, X, max_iter, max_time):
         W_in, T_in = self._warm_start()
-        X = self._prepare_fit(X)
+        kw = dict(self._preprocess_kwargs(), **self.nmf_kwargs)
         soln = _nmf(X, self.k, max_iter=max_iter, max_time=max_time, project_W_each_iter=False,
                     w_row_sum=1.0, project_T_each_iter=True, t_row_sum=1.0,
                     do_final_project_W=self.do_final_project_W, W_in=W_in, T_in=T_in,
                     reg_w_l1=self.wr1, reg_w_l2=self.wr2, reg_t_l1=self.tr1, reg_t_l2=self.tr2,
-                    random_state=self.random_state, **self.nmf_kwargs)
+                    random_state=self.random_state, **kw)
+        if self.handle_tfidf:
+            self.idf = soln['idf']
         self._keep(soln)
 
     def fit_transform(self, X, y=None):
@@ -220,14 +223,11 @@ class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.Tra
 
     def transform(self, Xnew):
         """express Xnew in the fitted topics (4 sweeps over W with T fixed)"""
-        if self.handle_tfidf:
-            Xnew = Xnew * self.idf
-        if self.handle_normalization:
-            Xnew = normalize(Xnew)
         soln = _nmf(Xnew, self.k, max_iter=4, max_time=7200, project_W_each_iter=False, w_row_sum=1.0,
                     t_row_sum=1.0, T_in=self.T, do_final_project_W=self.do_final_project_W, fix_T=True,
                     reg_w_l1=self.wr1, reg_w_l2=self.wr2, reg_t_l1=self.tr1, reg_t_l2=self.tr2,
-                    random_state=self.random_state)
+                    random_state=self.random_state,
+                    **self._preprocess_kwargs(idf=self.idf if self.handle_tfidf else None))
         return soln['W']
 
     def constrained_transform(self, X):

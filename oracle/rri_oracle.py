@@ -366,8 +366,14 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False, random_state=Non
         do_final_project_W=True, project_T_each_iter=False, t_row_sum=None,
         early_stop=None, reset_topic_method='max_resid_document', fix_reset_seed=False,
         n_resets=23, reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0, diagnostics=[],
-        objective_always=False, on_sweep=None, eps_gauss_t=None, delta_gauss_t=None):
-    """Restatement of nmf.py:98-560 (store_gradients omitted: the reference cannot return from such a call).
+        objective_always=False, on_sweep=None, eps_gauss_t=None, delta_gauss_t=None,
+        store_gradients=False, ind_rows_to_store=None):
+    """Restatement of nmf.py:98-560.
+
+    store_gradients (nmf.py:325-327, 411-413, 454-456, 677-686, 706-713, 541-549): the reference raises IndexError
+    at :543, where the reshape lambda meant as stack_matrices' `transform` is passed as `dict_key`; this restates
+    the evident intent -- out['numer_W'][sweep] the k stacked wR_store rows, out['denom_W'][sweep] the k nw_store
+    (k x 1, or k x d for weighted problems).  Not pinned by the reference (it cannot produce these).
 
     `objective_always=True` reproduces the reference AS SHIPPED, whose module
     logger has level NOTSET so `logger.level <= logging.DEBUG` (nmf.py:366) forces
@@ -388,6 +394,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False, random_state=Non
         diagnostics = [diagnostics]
     if diagnostics:
         out['diagnostics'] = {f.__name__: [] for f in diagnostics}
+    if store_gradients:
+        out['numer_W'], out['denom_W'] = {}, {}
     if random_state is None:
         random_state = int(time.time()) % 4294967296
     t0_wall = time.time()
@@ -435,9 +443,20 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False, random_state=Non
             last_score = score
             W_prev, T_prev = copy.deepcopy(W), copy.deepcopy(T)
 
+        if store_gradients:
+            out['numer_W'][iter_no], out['denom_W'][iter_no] = [], []
         for t in range(k):  # nmf.py:415-476
             if not fix_T:
                 wR, nw = residual_products_T(X, W, T, t, W_mat)
+                if store_gradients:
+                    if ind_rows_to_store is None:
+                        wR_store, nw_store = wR, nw
+                    else:   # the same sums over the listed rows only (nmf.py:680-686, 709-713)
+                        r_ = np.asarray(ind_rows_to_store)
+                        wR_store, nw_store = residual_products_T(X[r_, :], W[r_, :], T, t,
+                                                                 None if W_mat is None else W_mat[r_, :])
+                    out['numer_W'][iter_no].append(np.array(wR_store, dtype=np.float64))
+                    out['denom_W'][iter_no].append(np.array(nw_store, dtype=np.float64))
                 if eps_gauss_t and delta_gauss_t:   # nmf.py:422-435: Gaussian mechanism on the T-row sums
                     from scipy.stats import norm as gaussian
                     c2 = 2 * np.log(1.25 / float(delta_gauss_t)) + 0.001
@@ -492,6 +511,11 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False, random_state=Non
         obj_history.extend(sub['obj_history'] if 'obj_history' in sub else [])
         iter_cputime.extend(sub['iter_cputime'])
         W = sub['W']
+    if store_gradients:
+        as_row = lambda v: np.asarray(v, dtype=np.float64).reshape((1, np.size(v)))
+        for key in ('numer_W', 'denom_W'):
+            for it, rows in out[key].items():
+                out[key][it] = np.vstack([as_row(v) for v in rows]) if rows else np.zeros((0, 0))
     out['W'] = W
     out['T'] = T
     if compute_obj_each_iter:

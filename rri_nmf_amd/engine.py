@@ -383,9 +383,17 @@ class RRIEngine(object):
     def sweep_with_T_noise(self, draw):
         """One sweep in which every T-row step sees wR + noise and max(nw + noise, 0): the Gaussian mechanism of
         nmf.py:422-435.  `draw(m)` returns m samples; it is called in the reference's order (wR first, then nw,
-        after any reset of the previous column has drawn its own numbers).  The sums of a topic step are taken on
-        the device, perturbed in the reduce buffer on the host, and the step finishes on the device: the split
-        stepping of the row-sharded path with the host in the place of the all-reduce."""
+        after any reset of the previous column has drawn its own numbers)."""
+        self.sweep_stepwise(draw=draw)
+
+    def sweep_stepwise(self, draw=None, observe=None):
+        """One sweep with the host between the two device stages of every T-row step: the sums of a topic step are
+        taken on the device (rri_topic_reduce_local), read -- and, with `draw`, perturbed -- in the reduce buffer on the
+        host, and the step finishes on the device (rri_topic_finish): the split stepping of the row-sharded path with
+        the host in the place of the all-reduce.
+          observe(t, wR, nw)  sees the sums of _compute_update_T (nmf.py:670-676, 687-701) before any noise:
+                              store_gradients (nmf.py:454-456)
+          draw(m)             the Gaussian mechanism (see sweep_with_T_noise)"""
         d, k = self.d, self.k
         ld = -(-d // (16 // self.dtype.itemsize)) * (16 // self.dtype.itemsize)
         for t in range(k):
@@ -397,19 +405,30 @@ class RRIEngine(object):
                 r = self.reduce_read(2 * ld)
                 trow = self.get_T()[t, :]
                 a, nw = r[:d], r[ld:ld + d]
-                wR = a + trow * nw + draw(d)
-                nw2 = np.maximum(nw + draw(d), 0)
-                r[:d] = wR - trow * nw2
-                r[ld:ld + d] = nw2
+                wR = a + trow * nw
+                if observe is not None:
+                    observe(t, wR.copy(), nw.copy())
+                if draw is not None:
+                    wR = wR + draw(d)
+                    nw2 = np.maximum(nw + draw(d), 0)
+                    r[:d] = wR - trow * nw2
+                    r[ld:ld + d] = nw2
             else:                                       # red = [w^T X | slices of (w^T W, ||w||^2, .)]
                 r = self.reduce_read(ld + _capi.RRI_GRAM_SLICES * (k + 2))
-                r[:d] += draw(d)                        # wR = w^T X - (w^T W) T: the noise passes through
                 at = [ld + g * (k + 2) + k for g in range(_capi.RRI_GRAM_SLICES)]
-                nw = float(sum(r[i] for i in at)) + float(np.asarray(draw(1)).ravel()[0])
-                for i in at:
-                    r[i] = 0.0
-                r[at[0]] = max(nw, 0.0)
-            self.reduce_write(r)
+                nw = float(sum(r[i] for i in at))
+                if observe is not None:
+                    wW = sum(r[ld + g * (k + 2):ld + g * (k + 2) + k] for g in range(_capi.RRI_GRAM_SLICES))
+                    wW[t] = 0.0                         # nmf.py:672
+                    observe(t, r[:d] - wW.dot(self.get_T()), nw)
+                if draw is not None:
+                    r[:d] += draw(d)                    # wR = w^T X - (w^T W) T: the noise passes through
+                    nw = nw + float(np.asarray(draw(1)).ravel()[0])
+                    for i in at:
+                        r[i] = 0.0
+                    r[at[0]] = max(nw, 0.0)
+            if draw is not None:
+                self.reduce_write(r)
             self.topic_finish(t)
             if self._stepping_event() is not None:      # the new T row was (numerically) zero: reset, then its W half
                 self.topic_finish_w(t)

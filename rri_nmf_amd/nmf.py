@@ -276,6 +276,39 @@ def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, projec
     return W, T
 
 
+def _gradient_recorder(eng, X, W_mat, rows, numer_out, denom_out):
+    """observe(t, wR, nw) for RRIEngine.sweep_stepwise: appends what _compute_update_T returns as wR_store, nw_store
+    (nmf.py:677-686, 706-713) -- the sums over all rows as they come from the device, or, with `ind_rows_to_store`,
+    the same sums over those rows only, taken on the host from the current factors"""
+    if rows is None:
+        def observe(t, wR, nw):
+            numer_out.append(wR)
+            denom_out.append(nw)
+        return observe
+    rows = np.asarray(rows)
+    Xs = X[rows, :]
+    Xs = Xs.toarray() if scipy.sparse.issparse(Xs) else np.asarray(Xs, dtype=np.float64)
+    Ms = None
+    if W_mat is not None:
+        Ms = W_mat[rows, :]
+        Ms = Ms.toarray() if scipy.sparse.issparse(Ms) else np.asarray(Ms, dtype=np.float64)
+
+    def observe(t, wR, nw):
+        Ws, T = eng.get_W()[rows, :], eng.get_T()
+        ws = Ws[:, t].copy()
+        if Ms is None:                            # nmf.py:680-686
+            wWs = ws.dot(Ws)
+            wWs[t] = 0
+            numer_out.append(ws.dot(Xs) - wWs.dot(T))
+            denom_out.append((ws ** 2).sum())
+        else:                                     # nmf.py:709-713
+            Wz = Ws.copy()
+            Wz[:, t] = 0
+            numer_out.append(ws.dot(Ms * (Xs - Wz.dot(T))))
+            denom_out.append((ws ** 2).dot(Ms))
+    return observe
+
+
 def _sentinel(W, T):
     return {'W': W, 'T': T, 'obj_history': [-np.inf], 'iter_cputime': [0]}
 
@@ -301,11 +334,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     (matrixops.py:124-179) before the factorisation -- {'tfidf': True | idf vector | False, 'normalize': bool} or
     the step names.  A dense X without weights or host callbacks is uploaded raw and rewritten in place on the
     device; every other case preprocesses on the host.  The idf used comes back as rtv['idf']."""
-    if store_gradients or ind_rows_to_store is not None:
-        # the reference cannot return from such a call: nmf.py:543 hands stack_matrices its reshape lambda as
-        # `dict_key`, which indexes an ndarray with it (IndexError) -- there is no behaviour to reproduce
-        raise NotImplementedError('store_gradients is not available on the device path '
-                                  '(SURVEY.md section 8f rank 4)')
+    if store_gradients and not fix_T and (fix_W or k < 2):
+        raise NotImplementedError('store_gradients needs both halves free and k >= 2 on the device path')
     draw_noise = None
     if eps_gauss_t and delta_gauss_t and not fix_T:
         # Gaussian mechanism on the T-row sums (nmf.py:422-435; Dwork & Roth p. 261)
@@ -327,7 +357,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     spec = _preprocess_spec(preprocess)
     device_spec = None
     if spec is not None:
-        host_callbacks = bool(diagnostics) or (callable(early_stop) and getattr(early_stop, 'device_entries', None) is None)
+        host_callbacks = bool(diagnostics) or bool(store_gradients) or \
+            (callable(early_stop) and getattr(early_stop, 'device_entries', None) is None)
         if scipy.sparse.issparse(X) or W_mat is not None or w_row is not None or host_callbacks:
             X, rtv['idf'] = _preprocess_on_host(X, *spec)
         else:
@@ -356,6 +387,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         diagnostics = [diagnostics]
     if diagnostics:
         rtv['diagnostics'] = {f.__name__: [] for f in diagnostics}
+    if store_gradients:                          # nmf.py:325-327
+        rtv['numer_W'], rtv['denom_W'] = {}, {}
     if random_state is None:
         random_state = int(time.time()) % 4294967296
 
@@ -440,10 +473,16 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
                 eng.snapshot()
 
             sweep_t0 = time.time()
-            if draw_noise is None:
+            observe = None
+            if store_gradients:                   # nmf.py:411-413, 454-456: the sums behind every T-row update
+                numer_it, denom_it = [], []
+                rtv['numer_W'][iter_no], rtv['denom_W'][iter_no] = numer_it, denom_it
+                if not fix_T:
+                    observe = _gradient_recorder(eng, X, W_mat, ind_rows_to_store, numer_it, denom_it)
+            if draw_noise is None and observe is None:
                 eng.sweep(1)                      # the topic loop, nmf.py:415-476
             else:
-                eng.sweep_with_T_noise(draw_noise)
+                eng.sweep_stepwise(draw=draw_noise, observe=observe)
 
             if project_W_each_iter and not fix_W and w_row_sum is not None:   # nmf.py:481-484
                 eng.project_W_rows(w_row_sum if np.isscalar(w_row_sum) else w_row_sum.ravel())
@@ -482,6 +521,14 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         iter_cputime.extend(sub['iter_cputime'])
         W = sub['W']
 
+    if store_gradients:
+        # nmf.py:541-549 means to stack the k row vectors of a sweep (its reshape lambda is passed in the place of
+        # `dict_key`, which raises; as `transform` it gives this): numer_W[sweep] is k x d, denom_W[sweep] k x 1
+        # (k x d for weighted problems)
+        as_row = lambda v: np.asarray(v, dtype=np.float64).reshape((1, np.size(v)))
+        for key in ('numer_W', 'denom_W'):
+            for it, rows in rtv[key].items():
+                rtv[key][it] = np.vstack([as_row(v) for v in rows]) if rows else np.zeros((0, 0))
     rtv['W'] = W
     rtv['T'] = T
     if compute_obj_each_iter:

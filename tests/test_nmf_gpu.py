@@ -356,5 +356,51 @@ def test_gaussian_mechanism_against_the_reference():
             (name, relfro(r['W'], g[name + '_W']), relfro(r['T'], g[name + '_T']))
     with pytest.raises(NotImplementedError):
         nmf_mod.nmf(cases[0][1], k, W_in=W0, T_in=T0, fix_W=True, max_iter=1, eps_gauss_t=1.0, delta_gauss_t=0.1)
+
+
+def test_store_gradients_matches_the_oracle():
+    """store_gradients / ind_rows_to_store (nmf.py:411-413, 454-456, 677-686, 706-713): the sums behind every T-row
+    update, read from the device between the two stages of the step.  The reference itself raises at nmf.py:543 (its
+    reshape lambda is passed as `dict_key`); oracle and device restate the evident intent."""
+    import scipy.sparse as sp
+    nmf_mod, _ = api()
+    orc = oracle()
+    n, d, k = 90, 41, 4
+    X = planted_X(n, d, k, seed=5, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=6)
+    M = (np.random.RandomState(7).rand(n, d) < 0.4).astype(np.float64)
+    rows = [3, 17, 18, 60]
+    tm = dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)
+    cases = [('plain', None, {}, None), ('plain, rows', None, {}, rows), ('topic model', None, tm, None),
+             ('weighted', M, dict(t_row_sum=1.0, reset_topic_method=None), None),
+             ('weighted, rows', M, dict(t_row_sum=1.0, reset_topic_method=None), rows)]
+    for name, Wm, kw, r in cases:
+        Xc = X * Wm if Wm is not None else X
+        a = orc.nmf(Xc.copy(), k, W_in=W0.copy(), T_in=T0.copy(), W_mat=Wm, max_iter=3, store_gradients=True,
+                    ind_rows_to_store=r, **kw)
+        b = nmf_mod.nmf(Xc, k, W_in=W0, T_in=T0, W_mat=Wm, max_iter=3, store_gradients=True, ind_rows_to_store=r, **kw)
+        assert sorted(b['numer_W']) == sorted(a['numer_W']) == [0, 1, 2], name
+        for it in a['numer_W']:
+            assert b['numer_W'][it].shape == a['numer_W'][it].shape == (k, d), name
+            assert b['denom_W'][it].shape == a['denom_W'][it].shape == ((k, d) if Wm is not None else (k, 1)), name
+            assert relfro(b['numer_W'][it], a['numer_W'][it]) < 1e-9, (name, it)
+            assert relfro(b['denom_W'][it], a['denom_W'][it]) < 1e-9, (name, it)
+        assert relfro(b['W'], a['W']) < 1e-8 and relfro(b['T'], a['T']) < 1e-8, name
+    # the pattern-only weighted handle records the same sums as the dense one
+    kw = dict(t_row_sum=1.0, reset_topic_method=None, max_iter=2, store_gradients=True, W_in=W0, T_in=T0)
+    dense = nmf_mod.nmf(X * M, k, W_mat=M, **kw)
+    sparse = nmf_mod.nmf(sp.csr_matrix(X * M), k, W_mat=sp.csr_matrix(M), sparse_pattern=True, **kw)
+    for it in dense['numer_W']:
+        assert relfro(sparse['numer_W'][it], dense['numer_W'][it]) < 1e-9
+        assert relfro(sparse['denom_W'][it], dense['denom_W'][it]) < 1e-12
+    # stored before the Gaussian mechanism perturbs them (nmf.py:419-435 come after _compute_update_T)
+    np.random.seed(3)
+    noisy = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, store_gradients=True, eps_gauss_t=1e6, delta_gauss_t=0.5)
+    quiet = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, store_gradients=True)
+    assert np.allclose(noisy['numer_W'][0][0], quiet['numer_W'][0][0], rtol=1e-12)
+    # ind_rows_to_store alone stores nothing (nmf.py:325: only store_gradients switches it on); T fixed: nothing to store
+    assert 'numer_W' not in nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, ind_rows_to_store=rows)
+    fixed = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, fix_T=True, store_gradients=True)
+    assert fixed['numer_W'][0].size == 0
     with pytest.raises(NotImplementedError):
-        nmf_mod.nmf(cases[0][1], k, W_in=W0, T_in=T0, max_iter=1, store_gradients=True)
+        nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, fix_W=True, store_gradients=True)

@@ -259,3 +259,31 @@ def test_gaussian_mechanism():
         np.random.seed(int(g['seed'][0]))
         r = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), W_mat=M, **kw)
         assert same(r['W'], g[name + '_W']) and same(r['T'], g[name + '_T']), name
+
+
+def test_oracle_store_gradients_restates_the_intended_stacks():
+    """store_gradients has no vectors from the reference (it raises at nmf.py:543): the oracle's restatement is checked
+    against the definitions of wR_store / nw_store (nmf.py:670-686) on the first topic step, where W and T are the
+    starting factors"""
+    from rri_nmf_amd.synthetic import planted_X, scaled_init
+    n, d, k = 40, 23, 3
+    X = planted_X(n, d, k, seed=1, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=2)
+    rows = [1, 5, 30]
+    full = orc.nmf(X.copy(), k, W_in=W0.copy(), T_in=T0.copy(), max_iter=2, store_gradients=True)
+    part = orc.nmf(X.copy(), k, W_in=W0.copy(), T_in=T0.copy(), max_iter=2, store_gradients=True, ind_rows_to_store=rows)
+    W0c, T0c = np.maximum(W0, 0), np.maximum(T0, 0)
+    g = W0c[:, 0] @ W0c
+    g[0] = 0
+    assert np.allclose(full['numer_W'][0][0], W0c[:, 0] @ X - g @ T0c, rtol=1e-13)
+    assert np.allclose(full['denom_W'][0][0], (W0c[:, 0] ** 2).sum(), rtol=1e-13)
+    gs = W0c[rows, 0] @ W0c[rows, :]
+    gs[0] = 0
+    assert np.allclose(part['numer_W'][0][0], W0c[rows, 0] @ X[rows, :] - gs @ T0c, rtol=1e-13)
+    assert full['numer_W'][1].shape == (k, d) and full['denom_W'][1].shape == (k, 1)
+    assert np.array_equal(full['W'], part['W'])          # recording changes nothing
+    M = (np.random.RandomState(3).rand(n, d) < 0.5).astype(float)
+    w = orc.nmf(X * M, k, W_in=W0.copy(), T_in=T0.copy(), W_mat=M, max_iter=1, t_row_sum=1.0,
+                reset_topic_method=None, store_gradients=True)
+    assert w['numer_W'][0].shape == (k, d) and w['denom_W'][0].shape == (k, d)
+    assert np.allclose(w['denom_W'][0][0], (W0c[:, 0] ** 2) @ M, rtol=1e-13)

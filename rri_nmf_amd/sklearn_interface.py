@@ -10,7 +10,6 @@ from sklearn.model_selection import train_test_split
 from sklearn.utils.validation import check_X_y, check_array
 
 from . import nmf as _nmf_module
-from .matrixops import tfidf, normalize
 
 
 def _nmf(*a, **kw):

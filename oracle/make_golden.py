@@ -8,7 +8,8 @@ the reference itself, run here through oracle/ref_loader.py.
 Groups: G1 TM estimator fit, G2 TM transform, G3 the four
 TM convergence settings, G4 the four WRRI settings + the RS estimator, G5 plain
 RRI on seeded synthetic X, G6 rare branches (c<=0, resets), G7 per-function
-vectors (qf_min, simplex projection), G8 init known-answer (tests/conftest.py).
+vectors (qf_min, simplex projection), G8 init known-answer (tests/conftest.py), G9 Gaussian mechanism,
+G10 the coherence beam-search initialiser.
 """
 import os
 import sys
@@ -364,7 +365,21 @@ def g9():
     save('g9_gaussian_mechanism', **out)
 
 
+# ---------------------------------------------------------------- G10
+def g10():
+    """init_coherence_beam_search (initialization.py:166-208): the stand-alone topic initialiser (not reachable
+    through initialize_nmf's `init` names), on seeded term counts and on the first rows of the text fixture"""
+    rs = np.random.RandomState(21)
+    Xa = rs.poisson(0.6, size=(120, 40)).astype(np.float64)
+    Xa[:, 7] *= 3
+    Wa, Ta = ref.initialization.init_coherence_beam_search(Xa.copy(), 3, n_words_beam=6)
+    Xb = fixture('text_data_train')[:60, :80].astype(np.float64)
+    Xb = Xb[:, Xb.sum(0) > 0]
+    Wb, Tb = ref.initialization.init_coherence_beam_search(Xb.copy(), 4, n_words_beam=5)
+    save('g10_coherence_init', Xa=Xa, Wa=Wa, Ta=Ta, Xb=Xb, Wb=Wb, Tb=Tb)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
     for g in which:
-        {'g1': g1_g2, 'g3': g3, 'g4': g4, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}[g]()
+        {'g1': g1_g2, 'g3': g3, 'g4': g4, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9, 'g10': g10}[g]()

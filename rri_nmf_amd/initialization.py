@@ -9,7 +9,7 @@ import numpy as np
 from sklearn.utils import check_random_state
 from sklearn.utils.extmath import randomized_svd, squared_norm
 
-from .matrixops import normalize
+from .matrixops import normalize, tfidf
 
 _KNOWN = (None, 'random', 'smart_random', 'nndsvd', 'nndsvda', 'nndsvdar')
 
@@ -139,3 +139,46 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, row_
         W[W == 0] = abs(fill * rng.randn(len(W[W == 0])) / 100)
         H[H == 0] = abs(fill * rng.randn(len(H[H == 0])) / 100)
     return W, (normalize(H) if row_normalize else H)
+
+
+def init_coherence_beam_search(X, n_components, n_words_beam=20):
+    """Topics seeded by a beam search for word sets of high pointwise mutual information
+    (initialization.py:166-208): every topic starts from the heaviest unused word of normalize(tfidf(X)) and takes,
+    n_words_beam - 1 times, the unused word with the best summed PMI against the words it already holds; T gives each
+    chosen word its global weight (rows normalised), W = normalize(max(X T^T, 0)).  Stand-alone, as in the reference
+    (no `init` name of initialize_nmf leads here): pass the result as W_in / T_in.
+
+    The reference scans the words in two Python loops; here one topic step scores all words at once, with the same
+    additions in the same order (the scores, and so the choices, are bit-identical) and np.argmax's first maximum in
+    the place of the scan's strict `>`."""
+    X = normalize(tfidf(np.asarray(X, dtype=np.float64)))
+    C = np.dot(X.T, X)
+    k = n_components
+    n, d = X.shape
+    P_i = np.log(C.sum(1) + np.spacing(1))
+    P_ij = np.log(C + np.spacing(1))
+    xs = X.sum(0)
+    chosen = []
+    for _ in range(k):
+        j = int(np.argmax(xs))
+        xs[j] = 0                              # a word serves one topic only
+        tpc = [j]
+        for _ in range(1, n_words_beam):
+            free = xs > 0
+            if not free.any():                 # (the reference fails here with a TypeError on xs[None])
+                raise ValueError('init_coherence_beam_search: fewer than k * n_words_beam usable words')
+            score = np.zeros(d)
+            for c in tpc:
+                score += (P_ij[:, c] - P_i) - P_i[c]
+            score[~free] = -np.inf
+            best = int(np.argmax(score))
+            tpc.append(best)
+            xs[best] = 0
+        chosen.append(tpc)
+    xs = X.sum(0)
+    T = np.zeros((k, d))
+    for t, tpc in enumerate(chosen):
+        T[t, tpc] = xs[tpc]                    # weight of a word in its topic: its global importance
+    T = normalize(T)
+    W = normalize(np.maximum(np.dot(X, T.T), 0))
+    return W, T

@@ -321,3 +321,18 @@ def test_preprocess_option_parsing_and_host_route():
     assert np.array_equal(out2, X * idf_in) and np.array_equal(idf2, idf_in)
     out3, idf3 = nmf_mod._preprocess_on_host(X, False, True)
     assert idf3 is None and np.array_equal(out3, normalize(X))
+
+
+def test_coherence_beam_search_initialiser_against_the_reference():
+    """init_coherence_beam_search (initialization.py:166-208) against vectors captured from the reference (G10)"""
+    from rri_nmf_amd.initialization import init_coherence_beam_search
+    g = load_golden('g10_coherence_init')
+    Wa, Ta = init_coherence_beam_search(g['Xa'].copy(), 3, n_words_beam=6)
+    assert np.array_equal(Ta > 0, g['Ta'] > 0)                     # the same words in the same topics
+    assert np.allclose(Ta, g['Ta'], rtol=1e-13, atol=0) and np.allclose(Wa, g['Wa'], rtol=1e-12, atol=1e-300)
+    Wb, Tb = init_coherence_beam_search(g['Xb'].copy(), 4, n_words_beam=5)
+    assert np.array_equal(Tb > 0, g['Tb'] > 0)
+    assert np.allclose(Tb, g['Tb'], rtol=1e-13, atol=0) and np.allclose(Wb, g['Wb'], rtol=1e-12, atol=1e-300)
+    assert np.allclose(Ta.sum(1), 1) and np.allclose(Wa.sum(1), 1) and (Ta > 0).sum(1).tolist() == [6, 6, 6]
+    with pytest.raises(ValueError):                                # more words asked for than there are
+        init_coherence_beam_search(g['Xa'][:, :5].copy(), 3, n_words_beam=6)

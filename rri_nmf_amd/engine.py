@@ -401,32 +401,21 @@ class RRIEngine(object):
             self.topic_finish(-1)                       # the column check of topic t-1 (nmf.py:471-476)
             if self._stepping_event() is not None:      # dead column: reset, then the sums again
                 self.topic_reduce_local(t)
-            if self.weighted:                           # red = [a | nw]; wR = a + t .* nw (rri_wrri_kernels.hpp)
-                r = self.reduce_read(2 * ld)
-                trow = self.get_T()[t, :]
-                a, nw = r[:d], r[ld:ld + d]
-                wR = a + trow * nw
-                if observe is not None:
-                    observe(t, wR.copy(), nw.copy())
-                if draw is not None:
-                    wR = wR + draw(d)
-                    nw2 = np.maximum(nw + draw(d), 0)
-                    r[:d] = wR - trow * nw2
-                    r[ld:ld + d] = nw2
-            else:                                       # red = [w^T X | slices of (w^T W, ||w||^2, .)]
-                r = self.reduce_read(ld + _capi.RRI_GRAM_SLICES * (k + 2))
+            r, wR, nw, trow = self._topic_sums(t, ld, with_wR=observe is not None or self.weighted)
+            if observe is not None:
+                observe(t, np.array(wR), np.array(nw) if self.weighted else nw)
+            if draw is not None and self.weighted:
+                wR = wR + draw(d)
+                nw2 = np.maximum(nw + draw(d), 0)
+                r[:d] = wR - trow * nw2
+                r[ld:ld + d] = nw2
+            elif draw is not None:
                 at = [ld + g * (k + 2) + k for g in range(_capi.RRI_GRAM_SLICES)]
-                nw = float(sum(r[i] for i in at))
-                if observe is not None:
-                    wW = sum(r[ld + g * (k + 2):ld + g * (k + 2) + k] for g in range(_capi.RRI_GRAM_SLICES))
-                    wW[t] = 0.0                         # nmf.py:672
-                    observe(t, r[:d] - wW.dot(self.get_T()), nw)
-                if draw is not None:
-                    r[:d] += draw(d)                    # wR = w^T X - (w^T W) T: the noise passes through
-                    nw = nw + float(np.asarray(draw(1)).ravel()[0])
-                    for i in at:
-                        r[i] = 0.0
-                    r[at[0]] = max(nw, 0.0)
+                r[:d] += draw(d)                        # wR = w^T X - (w^T W) T: the noise passes through
+                nw = nw + float(np.asarray(draw(1)).ravel()[0])
+                for i in at:
+                    r[i] = 0.0
+                r[at[0]] = max(nw, 0.0)
             if draw is not None:
                 self.reduce_write(r)
             self.topic_finish(t)
@@ -435,6 +424,32 @@ class RRIEngine(object):
         self.topic_reduce_local(0)                      # the last column's check rides on topic 0's sums
         self.topic_finish(-1)
         self._stepping_event()
+
+    def _topic_sums(self, t, ld, with_wR=True):
+        """(reduce buffer, wR, nw, T[t,:] or None) after rri_topic_reduce_local(t): the sums _compute_update_T returns
+        (nmf.py:670-676 plain, :687-701 weighted)"""
+        d, k = self.d, self.k
+        if self.weighted:                               # red = [a | nw]; wR = a + t .* nw (rri_wrri_kernels.hpp)
+            r = self.reduce_read(2 * ld)
+            trow = self.get_T()[t, :]
+            nw = r[ld:ld + d]
+            return r, r[:d] + trow * nw, nw, trow
+        r = self.reduce_read(ld + _capi.RRI_GRAM_SLICES * (k + 2))   # red = [w^T X | slices of (w^T W, ||w||^2, .)]
+        nw = float(sum(r[ld + g * (k + 2) + k] for g in range(_capi.RRI_GRAM_SLICES)))
+        wR = None
+        if with_wR:
+            wW = sum(r[ld + g * (k + 2):ld + g * (k + 2) + k] for g in range(_capi.RRI_GRAM_SLICES))
+            wW[t] = 0.0                                 # nmf.py:672
+            wR = r[:d] - wW.dot(self.get_T())
+        return r, wR, nw, None
+
+    def topic_sums(self, t):
+        """(wR, nw) of topic t for the factors now on the device: w_t^T (X - sum_{j != t} w_j t_j) and ||w_t||^2, or
+        their weighted counterparts (d-vectors)"""
+        ld = -(-self.d // (16 // self.dtype.itemsize)) * (16 // self.dtype.itemsize)
+        self.topic_reduce_local(t)
+        _, wR, nw, _ = self._topic_sums(t, ld)
+        return np.array(wR), (np.array(nw) if self.weighted else nw)
 
     def topic_finish_w(self, t):
         self._check(self._lib.rri_topic_finish_w(self._h, int(t)))

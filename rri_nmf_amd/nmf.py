@@ -309,6 +309,31 @@ def _gradient_recorder(eng, X, W_mat, rows, numer_out, denom_out):
     return observe
 
 
+def _compute_update_T(X, W, T, t, store_gradients=False, ind_rows_to_store=None, W_mat=None, **kwargs):
+    """(wR, nw, wR_store, nw_store) of nmf.py:633-715 for the given factors: the sums behind the update of row t of T,
+    `w_t^T (X - sum_{j != t} w_j t_j)` and `||w_t||^2` (weighted: through the masked residual, both d-vectors), taken on
+    the device.  The reference's test file imports this name; nmf() itself steps on the device and does not call it.
+    `dtype=` / `device=` as for nmf(); other keywords (the reference passes its `locals()`) are ignored."""
+    X = X.tocsr() if scipy.sparse.issparse(X) else np.asarray(X)
+    W_mat = _sparse_mask_or_dense(W_mat)
+    W, T = np.asarray(W, dtype=np.float64), np.asarray(T, dtype=np.float64)
+    k = W.shape[1]
+    if not 0 <= int(t) < k:
+        raise IndexError('topic index out of range')
+    sdt = _storage_dtype(X, kwargs.get('dtype'))
+    with _engine_with_problem(X, W_mat, k, sdt, kwargs.get('device', 0), kwargs.get('sparse_pattern')) as eng:
+        eng.set_W(W)
+        eng.set_T(T)
+        eng.set_params(reset_topic_method=None)
+        wR, nw = eng.topic_sums(int(t))
+        wR_store = nw_store = None
+        if store_gradients:
+            numer, denom = [], []
+            _gradient_recorder(eng, X, W_mat, ind_rows_to_store, numer, denom)(int(t), wR, nw)
+            wR_store, nw_store = numer[0], denom[0]
+    return wR, nw, wR_store, nw_store
+
+
 def _sentinel(W, T):
     return {'W': W, 'T': T, 'obj_history': [-np.inf], 'iter_cputime': [0]}
 

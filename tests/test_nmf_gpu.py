@@ -404,3 +404,13 @@ def test_store_gradients_matches_the_oracle():
     assert fixed['numer_W'][0].size == 0
     with pytest.raises(NotImplementedError):
         nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, fix_W=True, store_gradients=True)
+    # the single-step helper the reference's test file imports (nmf.py:633-715)
+    for Wm in (None, M):
+        Xc = X * Wm if Wm is not None else X
+        for t in (0, k - 1):
+            want = orc.residual_products_T(Xc, W0.copy(), T0, t, Wm)
+            wR, nw, wRs, nws = nmf_mod._compute_update_T(Xc, W0, T0, t, True, rows, W_mat=Wm, iter_no=0, unused='x')
+            assert np.allclose(wR, want[0], rtol=1e-11, atol=1e-12) and np.allclose(nw, want[1], rtol=1e-12)
+            sub = orc.residual_products_T(Xc[rows], W0[rows].copy(), T0, t, None if Wm is None else Wm[rows])
+            assert np.allclose(wRs, sub[0], rtol=1e-11, atol=1e-12) and np.allclose(nws, sub[1], rtol=1e-12)
+    assert nmf_mod._compute_update_T(X, W0, T0, 1, False, None)[2:] == (None, None)

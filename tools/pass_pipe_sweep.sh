@@ -1,5 +1,6 @@
 #!/bin/bash
-# workgroup counts for the double-buffered pass (3 waves per SIMD by its registers) at C3; compare inside one call only
+# workgroup counts of the pass at C3, two repetitions (used for the double-buffered variant recorded in DESIGN.md
+# section 4; works on any build); compare inside one call only
 for rep in 1 2; do
 for wgs in 2048 1536 768 2304 3072 1024; do
   RRI_PASS_WGS=$wgs timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > /tmp/r1.json 2>/dev/null || exit 1

@@ -433,3 +433,31 @@ def test_the_abi_from_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     tag, o0, o1, cw, ct = r.stdout.split()
     assert tag == 'ok' and float(o1) < 0.2 * float(o0) and float(cw) > 0 and float(ct) > 0
+
+
+def test_bench_line_keeps_its_contract():
+    """`python bench.py` prints ONE JSON line with the keys the driver reads, the roofline and cpu_baseline objects
+    included (smallest BASELINE configuration, a few steps)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c2', '--steps', '3', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key, typ in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int),
+                     ('ms_per_step', float), ('higher_is_better', bool), ('scaling', str), ('dtype', str),
+                     ('data', str), ('config', dict), ('roofline', dict), ('cpu_baseline', dict)):
+        assert isinstance(j[key], typ), key
+    assert j['vs_baseline'] is None and j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 1
+    assert j['higher_is_better'] is True and j['scaling'] in ('weak', 'strong') and 'workload' in j['config']
+    assert abs(j['ms_per_step'] * j['value'] - 1e3) < 1e-6 * 1e3          # sweeps/s and ms per sweep agree
+    r = j['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] > 0 and r['achieved'] > 0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 'traffic' in r
+    c = j['cpu_baseline']
+    assert c['value'] > 0 and c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['unit'] == j['unit'] and c['sample']

@@ -32,6 +32,25 @@ __device__ __forceinline__ double lane_get(double v, int lane) {
 __device__ __forceinline__ int lane_get(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 // Sum over the 64 lanes of a FULLY ACTIVE wave; result returned wave-uniform.
+// Sum of p[i * stride] for i = i0, i0 + step, ... < i1, added IN THAT ORDER (bit-identical to the plain loop), with
+// B loads in flight: the plain loop compiles to one load and a full wait per iteration -- a dependent round trip to
+// L2 / HBM per term, which is what the small per-topic kernels spent their time on (k_trow_small 9 us at 10000 x 1000).
+template <int B>
+__device__ __forceinline__ double ordered_sum(const double* __restrict__ p, long long stride, int i0, int i1, int step) {
+    double a = 0.0;
+    for (int i = i0; i < i1; i += step * B) {
+        double v[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+            const int ii = i + q * step;
+            v[q] = ii < i1 ? p[(long long)ii * stride] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < B; ++q) a += v[q];
+    }
+    return a;
+}
+
 template <typename S>
 __device__ __forceinline__ S wave_sum(S v) {
     v += dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]

@@ -126,7 +126,7 @@ __device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ld
     if (threadIdx.x == 0) Ttpart[split * k + l] = acc;
     if (finish && l == 0 && split == 0) {
         double ps = 0.0;
-        for (int b = threadIdx.x; b < nblk; b += 256) ps += tpart[b];
+        ps = ordered_sum<4>(tpart, 1, threadIdx.x, nblk, 256);
         ps = block_sum(ps, scratch);
         if (threadIdx.x == 0) {
             const int mode = st->tmode;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_row_inverse(const double* __restrict__ 
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double xs = 0.0;
-    for (int q = 0; q < npanels; ++q) xs += Ypart[(i64)q * n + i];
+    xs = ordered_sum<8>(Ypart + i, n, 0, npanels, 1);
     xs += 2.220446049250313e-16;                      // np.spacing(1), matrixops.py:140
     inv[i] = xs < 1e-10 ? -1.0 : 1.0 / xs;
 }
@@ -427,9 +427,7 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
     for (int l = tid; l < k + 2; l += 256) gsh[l] = 0.0;
     if (UPDATE) {
         for (int l = tid; l < k; l += 256) {
-            double a = 0.0;
-            for (int q = 0; q < nsplit; ++q) a += Ttpart[q * k + l];
-            tts[l] = a;                               // entry t holds ||T[t,:]||^2 until zeroed below
+            tts[l] = ordered_sum<8>(Ttpart + l, k, 0, nsplit, 1);                               // entry t holds ||T[t,:]||^2 until zeroed below
         }
         __syncthreads();
         cden = tts[t] + p.reg_w_l2;                   // denom = nt + reg_w_l2 (nmf.py:465)
@@ -455,8 +453,7 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
         const bool valid = i < n;
         const double wn = (CARRY && valid) ? Wt[(i64)tn * ldw + i] : 0.0;
         double y = 0.0;
-        if (UPDATE && wave == 0 && valid)
-            for (int q = 0; q < npanels; ++q) y += Ypart[(i64)q * n + i];
+        if (UPDATE && wave == 0 && valid) y = ordered_sum<8>(Ypart + i, n, 0, npanels, 1);
         double dotv = 0.0;
         for (int l0 = wave; l0 < k; l0 += 4 * CH) {
             double wl[CH];
@@ -532,8 +529,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ Zpar
         const int c = tid & 31, g = tid >> 5;
         const i64 j = (i64)blockIdx.x * 32 + c;
         double a = 0.0;
-        if (j < ldz)
-            for (int b = g; b < nrb; b += 32) a += Zpart[(i64)b * ldz + j];
+        if (j < ldz) a = ordered_sum<8>(Zpart + j, ldz, g, nrb, 32);
         sh[g * 33 + c] = a;
         __syncthreads();
         if (tid < 32 && j < ldz) {   // here c == tid
@@ -550,8 +546,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ Zpar
         for (int l0 = 0; l0 < k + 2; l0 += 64) {
             const int l = l0 + lane;
             double a = 0.0;
-            if (l < k + 2)
-                for (int b = b0 + wave; b < b1; b += 16) a += Gpart[(i64)b * (k + 2) + l];
+            if (l < k + 2) a = ordered_sum<8>(Gpart + l, k + 2, b0 + wave, b1, 16);
             __syncthreads();
             sh[wave * 64 + lane] = a;
             __syncthreads();
@@ -688,8 +683,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
     for (int l0 = 0; l0 < k + 2; l0 += 32) {
         const int l = l0 + cc;
         double a = 0.0;
-        if (l < k + 2)
-            for (int b = g; b < nwb; b += 32) a += Gpart[(i64)b * (k + 2) + l];
+        if (l < k + 2) a = ordered_sum<8>(Gpart + l, k + 2, g, nwb, 32);
         __syncthreads();
         sh[g * 33 + cc] = a;
         __syncthreads();
@@ -735,8 +729,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
     const i64 j = (i64)blockIdx.x * 32 + cc;
     {
         double a = 0.0;
-        if (j < ldz)
-            for (int b = g; b < nrb; b += 32) a += Zpart[(i64)b * ldz + j];
+        if (j < ldz) a = ordered_sum<8>(Zpart + j, ldz, g, nrb, 32);
         sh[g * 33 + cc] = a;
     }
     __syncthreads();
@@ -750,8 +743,19 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
     {
         double a = 0.0;
         if (j < d)
-            for (int l = g; l < k; l += 32)
-                if (l != t) a = fma(gsh[l], T[(i64)l * ldt + j], a);
+            for (int l0 = g; l0 < k; l0 += 32 * 4) {   // 4 rows of T in flight, added in topic order
+                double tv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int l = l0 + 32 * q;
+                    tv[q] = (l < k && l != t) ? T[(i64)l * ldt + j] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int l = l0 + 32 * q;
+                    if (l < k && l != t) a = fma(gsh[l], tv[q], a);
+                }
+            }
         sh[g * 33 + cc] = a;
     }
     __syncthreads();
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(1024) void k_trow_final(double* __restrict__ T, i64
         row_dirty = true;
     } else {
         double ps = 0.0;
-        for (int b = tid; b < nblk; b += blockDim.x) ps += tpart[b];
+        ps = ordered_sum<4>(tpart, 1, tid, nblk, (int)blockDim.x);
         ps = block_sum(ps, scratch);
         if (mode == 0) nx = ps;
         sumT = ps;
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ G
     if (st->halt) return;
     __shared__ double scratch[40];
     double a = 0.0;
-    for (int b = threadIdx.x; b < nwb; b += blockDim.x) a += Gpart[(i64)b * (k + 2) + k + 1];
+    a = ordered_sum<8>(Gpart + k + 1, k + 2, threadIdx.x, nwb, (int)blockDim.x);
     a = block_sum(a, scratch);
     if (threadIdx.x == 0) {
         const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
@@ -1411,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, i64 
 __global__ __launch_bounds__(256) void k_rows_sum(const double* __restrict__ part, int nb, double* __restrict__ out) {
     __shared__ double scratch[40];
     double s = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 256) s += part[(i64)blockIdx.x * nb + b];
+    s = ordered_sum<8>(part + (i64)blockIdx.x * nb, 1, threadIdx.x, nb, 256);
     s = block_sum(s, scratch);
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }

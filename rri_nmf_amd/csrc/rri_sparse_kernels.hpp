@@ -249,9 +249,7 @@ __global__ __launch_bounds__(256) void k_sp_sum_blocks(const double* __restrict_
                                                        double* __restrict__ res) {
     const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
     if (e >= count) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(i64)b * count + e];
-    res[e] = s;
+    res[e] = ordered_sum<8>(part + e, count, 0, nblk, 1);
 }
 
 // the reset row max(X[mi,:] - W[mi,:] T, 0) (nmf.py:770-775) from the pattern of row mi = *row_idx; out has d

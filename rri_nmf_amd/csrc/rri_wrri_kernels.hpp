@@ -330,8 +330,7 @@ __global__ __launch_bounds__(256) void k_wwcol(double* __restrict__ Wt, i64 ldw,
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     double wnew = 0.0, neg = 0.0;
     if (i < n) {
-        double b = 0.0, nt = 0.0;
-        for (int q = 0; q < npg; ++q) { b += Ypart[(i64)q * n + i]; nt += Y2part[(i64)q * n + i]; }
+        const double b = ordered_sum<8>(Ypart + i, n, 0, npg, 1), nt = ordered_sum<8>(Y2part + i, n, 0, npg, 1);
         const double w0 = Wt[(i64)t * ldw + i];
         const double numer = fma(w0, nt, b) - p.reg_w_l1;
         const double c = nt + p.reg_w_l2;
@@ -375,10 +374,8 @@ __global__ __launch_bounds__(256) void k_wcheck_wcol(const double* __restrict__ 
     if (st->halt) return;
     __shared__ double scratch[40];
     double a = 0.0, f = 0.0;
-    for (int b = threadIdx.x; b < nwb; b += blockDim.x) {
-        a += Gpart[(i64)b * (k + 2) + k + 1];
-        f += Gpart[(i64)b * (k + 2) + k];
-    }
+    a = ordered_sum<8>(Gpart + k + 1, k + 2, threadIdx.x, nwb, (int)blockDim.x);
+    f = ordered_sum<8>(Gpart + k, k + 2, threadIdx.x, nwb, (int)blockDim.x);
     a = block_sum(a, scratch);
     f = block_sum(f, scratch);
     if (threadIdx.x == 0) {

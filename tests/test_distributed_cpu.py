@@ -118,7 +118,8 @@ def _worker(rank, world, port, n, d, k, sweeps, out_dir, reg_w_l1=0.0):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     X = planted_X(n, d, k, seed=0, dtype=np.float64)
     W0, T0 = scaled_init(X, k, seed=1)
     lo, hi = shard_rows(n, world, rank)

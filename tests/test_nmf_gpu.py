@@ -156,10 +156,13 @@ def test_errors_raised_like_the_reference():
                     w_row_sum=1.0, reg_t_l2=-50.0)
 
 
+@pytest.mark.timeout(180)
 def test_sharded_stepping_single_rank_matches_sweep():
     """the split step protocol (reduce -> [all-reduce] -> finish) gives what rri_sweep gives; run with a
-    one-rank gloo group so the collective is exercised on the engine's torch stream"""
+    one-rank RCCL group so the collective is exercised on the engine's torch stream"""
+    import datetime
     import os
+    import socket
     import torch
     import torch.distributed as dist
     from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
@@ -171,9 +174,11 @@ def test_sharded_stepping_single_rank_matches_sweep():
         e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params()
         e.sweep(3)
         Wa, Ta, obja = e.get_W(), e.get_T(), e.objective()
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29617')
-    dist.init_process_group('nccl', rank=0, world_size=1)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:      # a free port: nothing is assumed about the box
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            timeout=datetime.timedelta(seconds=90), device_id=torch.device('cuda', 0))
     try:
         eng, red, stream = make_device_shard(n, d, k, dtype=np.float32, device_index=0)
         eng.upload_X(X); eng.set_W(W0); eng.set_T(T0); eng.set_params()
@@ -228,11 +233,14 @@ def test_convergence_RS_Estimator():
     assert Wnew.shape == (n, 5) and Wnew.min() >= 0
 
 
+@pytest.mark.timeout(180)
 def test_sharded_resets_match_single_call_path():
     """reset events in the row-sharded stepping (resolved collectively by ShardedRRI) give what rri_sweep's own
     pause / resolve / resume gives: W columns killed (events noticed by the next T-row step, the last one by the
     final check) and T rows killed (events inside a topic step)"""
-    import os
+    import datetime
+    import socket
+    import torch
     import torch.distributed as dist
     from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
     from rri_nmf_amd.engine import RRIEngine
@@ -240,9 +248,11 @@ def test_sharded_resets_match_single_call_path():
     n, d, k = [int(v) for v in g['shape']]
     X = planted_X(n, d, k, seed=3, dtype=np.float64)
     W0, T0 = scaled_init(X, k, seed=4)
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29618')
-    dist.init_process_group('nccl', rank=0, world_size=1)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            timeout=datetime.timedelta(seconds=90), device_id=torch.device('cuda', 0))
     try:
         for flags, gW, gT in ((dict(t_row_sum=1.0, reg_w_l1=1e6), 'l1killW_mrd_W', 'l1killW_mrd_T'),
                               (dict(t_row_sum=1.0, reg_t_l1=1e6), 'l1kill_W', 'l1kill_T')):

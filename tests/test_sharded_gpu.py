@@ -40,7 +40,8 @@ def _worker(rank, world, port, n, d, k, sweeps, weighted, store, flags, out_dir)
     from rri_nmf_amd.distributed import ShardedRRI, make_device_shard, shard_rows
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
         lo, hi = shard_rows(n, world, rank)
@@ -82,7 +83,7 @@ CASES = {
 }
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(240)
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_two_shards_on_one_gpu_match_one_engine(name, tmp_path):
     import torch.multiprocessing as mp

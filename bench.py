@@ -151,6 +151,9 @@ def main():
     if sharded:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        # one node by contract (rendezvous on 127.0.0.1): RCCL's bootstrap socket stays on loopback too, whatever the
+        # container's hostname resolves to; the data path is xGMI / shared memory either way
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         if rehearsal:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:

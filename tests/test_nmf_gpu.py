@@ -177,6 +177,7 @@ def test_sharded_stepping_single_rank_matches_sweep():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:      # a free port: nothing is assumed about the box
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # one node: RCCL's bootstrap socket needs no other interface
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
                             timeout=datetime.timedelta(seconds=90), device_id=torch.device('cuda', 0))
     try:
@@ -239,6 +240,7 @@ def test_sharded_resets_match_single_call_path():
     pause / resolve / resume gives: W columns killed (events noticed by the next T-row step, the last one by the
     final check) and T rows killed (events inside a topic step)"""
     import datetime
+    import os
     import socket
     import torch
     import torch.distributed as dist
@@ -251,6 +253,7 @@ def test_sharded_resets_match_single_call_path():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # one node: RCCL's bootstrap socket needs no other interface
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
                             timeout=datetime.timedelta(seconds=90), device_id=torch.device('cuda', 0))
     try:

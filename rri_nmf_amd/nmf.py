@@ -199,8 +199,8 @@ def _preprocess_spec(preprocess):
         if unknown:
             raise ValueError('unknown preprocessing step(s): %s' % sorted(unknown))
         tfidf_opt, norm_opt = 'tfidf' in steps, 'normalize' in steps
-    if tfidf_opt is None:
-        tfidf_opt = False
+    if tfidf_opt is None or isinstance(tfidf_opt, (bool, np.bool_)):
+        tfidf_opt = bool(tfidf_opt)
     if tfidf_opt is False and not norm_opt:
         return None
     return tfidf_opt, norm_opt

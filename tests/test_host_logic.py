@@ -302,7 +302,7 @@ def test_preprocess_option_parsing_and_host_route():
     spec = nmf_mod._preprocess_spec
     assert spec(None) is None and spec({}) is None and spec({'tfidf': False, 'normalize': False}) is None
     assert spec('tfidf') == (True, False) and spec(('normalize', 'tfidf')) == (True, True)
-    assert spec({'normalize': 1}) == (False, True)
+    assert spec({'normalize': 1}) == (False, True) and spec({'tfidf': np.True_}) == (True, False)
     idf_in = np.arange(1.0, 7.0)
     got = spec({'tfidf': idf_in})
     assert got[0] is idf_in and got[1] is False

@@ -336,3 +336,26 @@ def test_coherence_beam_search_initialiser_against_the_reference():
     assert np.allclose(Ta.sum(1), 1) and np.allclose(Wa.sum(1), 1) and (Ta > 0).sum(1).tolist() == [6, 6, 6]
     with pytest.raises(ValueError):                                # more words asked for than there are
         init_coherence_beam_search(g['Xa'][:, :5].copy(), 3, n_words_beam=6)
+
+
+def test_dropin_alias_resolves_the_imports_of_the_reference_test_file():
+    """the import lines of the reference's tests (tests/test_nmf.py:3-6, tests/conftest.py:5) resolve against this
+    package once rri_nmf_amd.dropin is imported"""
+    import subprocess
+    import sys
+    code = ('import rri_nmf_amd.dropin\n'
+            'from rri_nmf.initialization import initialize_nmf\n'
+            'from rri_nmf.matrixops import proj_mat_to_simplex, normalize, tfidf\n'
+            'from rri_nmf.nmf import nmf, eps_div_by_zero, _compute_update_T\n'
+            'from rri_nmf.sklearn_interface import NMF_RS_Estimator, NMF_TM_Estimator\n'
+            'import rri_nmf, rri_nmf_amd, rri_nmf_amd.nmf as mine\n'
+            'assert rri_nmf is rri_nmf_amd and nmf is mine.nmf and eps_div_by_zero == mine.eps_div_by_zero\n'
+            'print("ok")\n')
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip() == 'ok', res.stderr[-1500:]
+    # it does not shadow another rri_nmf that is already there
+    code2 = ('import sys, types\nsys.modules["rri_nmf"] = types.ModuleType("rri_nmf")\n'
+             'try:\n    import rri_nmf_amd.dropin\nexcept ImportError as e:\n    print("refused")\n')
+    res = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip() == 'refused', res.stderr[-1500:]

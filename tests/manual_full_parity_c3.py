@@ -1,5 +1,5 @@
 """One-off: the device path against the CPU oracle at the FULL C3 size (100000 x 10000 fp32, k = 50), equal sweeps.
-The oracle needs ~16 s per sweep on the box's host cores; not part of the test suite.  usage: full_parity.py [sweeps]"""
+The oracle needs ~16 s per sweep on the box's host cores; not part of the test suite.  usage (from the repository root): python tests/manual_full_parity_c3.py [sweeps]"""
 import sys
 import time
 

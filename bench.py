@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- RRI sweeps/sec and achieved HBM GB/s of the MI355X path (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4|c5|c5s] [--schedule gram|residual]
 
 A step is one RRI sweep (k topic steps = k T-row + k W-column updates, nmf.py:415-476) over a
 synthetic dense fp32 X that is already resident in HBM when the timed region starts.
@@ -10,23 +10,27 @@ Workloads (BASELINE.json configs):
     c3 (default)  100000 x 10000, k=50: the roofline run the north_star target is quoted on.
                   N > 1: WEAK scaling -- every rank holds its own 100000-row shard of an
                   (N*100000) x 10000 problem (T replicated, one RCCL all-reduce of d+8(k+2) doubles per
-                  topic step).  `value` is the whole job's rate in sweeps/s of a 100000-row shard,
-                  i.e. N * (global sweeps/s): it equals plain sweeps/s at N = 1.
+                  topic step, inside rri_sweep).  `value` is the whole job's rate in sweeps/s of a 100000-row
+                  shard, i.e. N * (global sweeps/s): it equals plain sweeps/s at N = 1.
     c2            10000 x 1000, k=20 (X is Infinity-Cache resident: latency-, not HBM-bound).
     c4            1000000 x 10000, k=50 split by rows over the N ranks (STRONG scaling).
     c5            WRRI: c3's shape with a dense fp32 5 %-observed 0/1 mask, recommender flags (T clipped to
                   [0,1], no resets); single GPU.  Algorithmic bytes 5*n*d*4 per topic step.
+    c5s           the same problem on the observed pattern only (sparse-index formulation: its own byte figure).
+    --schedule residual   the explicit-residual form (one rank-one residual update pass per topic step, 2*n*d*4 B).
 
 Prints ONE JSON line on rank 0 (contract in the task description) including
-    roofline     : the dominant kernel (the fused X pass) -- algorithmic bytes n_local*d*4 per launch
-                   over its average duration, measured with HIP events on the kernel's stream
-                   inside the timed region, against 8 TB/s
-    cpu_baseline : the float64 numpy restatement (oracle/) timed on this box's host cores on a
-                   bounded row sample of the same X, scaled linearly in n to the full workload.
+    roofline      the dominant kernel -- algorithmic bytes per launch over its average duration, measured with HIP
+                  events on the kernel's stream inside the timed region, against 8 TB/s
+    cpu_baseline  the float64 numpy restatement (oracle/) timed on this box's host cores: c3 at FULL size (every
+                  row, `--cpu-sweeps` timed sweeps), the other workloads on the stated sample
+    parity_sample the device path against that CPU run after equal sweeps (same X, same start).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -48,6 +52,7 @@ CONFIGS = {
                      'figure than the dense c5 (SURVEY 8d)'),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PROFILE_ROUND = 'r02'
 
 
 def parse():
@@ -56,23 +61,45 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--schedule', default='gram', choices=['gram', 'residual'],
+                    help="gram: X is read once per topic step (default); residual: the explicit residual R = X - WT is "
+                         "updated by rank-one terms, one read-modify-write pass per topic step (unweighted, one GPU)")
     ap.add_argument('--cpu-sweeps', type=int, default=2)
-    ap.add_argument('--cpu-rows', type=int, default=10000, help='rows of X in the CPU baseline sample')
+    ap.add_argument('--cpu-rows', type=int, default=0,
+                    help='rows of X in the CPU baseline (0 = the workload default: all rows for c2 / c3, 100000 for c4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--storage', default='f32', choices=['f32', 'f64'],
                     help='storage type of X / mask / residual in HBM (the BASELINE configs are fp32; arithmetic is float64 either way)')
     ap.add_argument('--force-sharded', action='store_true',
-                    help='use the row-sharded driver (RCCL all-reduce per topic step) even with one rank')
+                    help='use the row-sharded path (an all-reduce per topic step) even with one rank')
+    ap.add_argument('--collective', default='library', choices=['library', 'torch'],
+                    help='row-sharded runs: library = RCCL inside librri_hip.so, the all-reduce enqueued by rri_sweep itself '
+                         '(default); torch = the caller-owned protocol, torch.distributed per topic step from Python')
     return ap.parse_args()
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
 
 
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child job.  Done before
     anything touches the GPU; the child is waited for, never exec'ed over this process."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 2000),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+def source_stamp():
+    """sha of the kernel sources: PMC traffic files carry the stamp of the build they were measured on"""
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, 'rri_nmf_amd', 'csrc')
+    for f in sorted(os.listdir(cs)):
+        h.update(open(os.path.join(cs, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def device_planted_shard(n_rows, d, k, seed, device):
@@ -94,35 +121,34 @@ def device_planted_shard(n_rows, d, k, seed, device):
     return X
 
 
-def cpu_baseline(Xs_host, W0s, T0, n_full, sweeps=2, threads=16):
-    """the numpy float64 restatement on the host cores: 1 warm-up + `sweeps` timed sweeps on the sample.
-    BLAS threads are capped at the box's CPU share for one GPU (16).  Also returns how far the SAME
-    restatement moves when its start is perturbed by one ulp: the iteration's own sensitivity, which
-    bounds the agreement any two implementations (or two BLAS builds) can show."""
+def relfro(a, b):
+    import numpy as np
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def cpu_plain(X_dev, W0, T0, rows, sweeps, threads, n_full, want_factors=True):
+    """the numpy float64 restatement (oracle/rri_oracle.py: the reference's operation order) on rows [0, rows) of the
+    resident X, `sweeps` timed sweeps one by one on `threads` BLAS threads.  Returns (rates per sweep, factors after
+    each sweep)."""
     import numpy as np
     from oracle import rri_oracle as orc
     from threadpoolctl import threadpool_limits
-    threads = int(min(threads, os.cpu_count() or threads))
-    X = Xs_host.astype(np.float64)
-    W, T = W0s.astype(np.float64).copy(), T0.astype(np.float64).copy()
+    X = np.empty((rows, X_dev.shape[1]), dtype=np.float64)
+    for lo in range(0, rows, 20000):                      # float64 on the host, chunk by chunk (no fp32 host copy of X)
+        hi = min(rows, lo + 20000)
+        X[lo:hi] = X_dev[lo:hi].cpu().numpy()
+    W, T = W0[:rows].astype(np.float64).copy(), T0.astype(np.float64).copy()
+    times, facs = [], []
     with threadpool_limits(limits=threads):
-        orc.plain_sweeps(X, W, T, 1)
-        t0 = time.perf_counter()
-        orc.plain_sweeps(X, W, T, sweeps)
-        dt = time.perf_counter() - t0
-        Wp = W0s.astype(np.float64) * (1.0 + 2.0 ** -52 * np.sign(np.random.RandomState(7).randn(*W0s.shape)))
-        Tp = T0.astype(np.float64).copy()
-        orc.plain_sweeps(X, Wp, Tp, 1 + sweeps)
-    rate_sample = sweeps / dt
-    frac = X.shape[0] / float(n_full)
-    sens = {'relfro_W': float(np.linalg.norm(Wp - W) / np.linalg.norm(W)),
-            'relfro_T': float(np.linalg.norm(Tp - T) / np.linalg.norm(T)),
-            'what': 'CPU restatement vs itself with W0 perturbed by 1 ulp, same sweeps'}
-    return dict(value=rate_sample * frac, unit='sweeps/s', cores=threads, kind='port',
-                sample='first %d of %d rows of the same X, %d timed sweeps after 1 warm-up, numpy float64 + '
-                       'OpenBLAS on %d threads (%d host cpus); sample rate %.3f sweeps/s scaled by %.4g '
-                       '(work is linear in n)' % (X.shape[0], n_full, sweeps, threads, os.cpu_count() or 0,
-                                                  rate_sample, frac)), W, T, sens
+        warm = min(rows, 2000)
+        orc.plain_sweeps(X[:warm].copy(), W[:warm].copy(), T.copy(), 1)       # BLAS threads up, pages of the code touched
+        for _ in range(sweeps):
+            t0 = time.perf_counter()
+            orc.plain_sweeps(X, W, T, 1)
+            times.append(time.perf_counter() - t0)
+            if want_factors:
+                facs.append((W.copy(), T.copy()))
+    return times, facs, X
 
 
 def main():
@@ -141,16 +167,22 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard, shard_rows
+    from rri_nmf_amd.distributed import RowGroup, ShardedRRI, make_device_shard, shard_rows
+    from rri_nmf_amd.engine import RRIEngine
 
     cfg = CONFIGS[args.config]
     d, k = cfg['d'], cfg['k']
+    weighted = bool(cfg.get('weighted'))
+    sparse = bool(cfg.get('sparse'))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     sharded = world > 1 or args.force_sharded
+    if args.schedule == 'residual' and (sharded or weighted):
+        sys.exit('--schedule residual is the unweighted flavour on one GPU')
     if sharded:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
+        if 'MASTER_PORT' not in os.environ:
+            os.environ['MASTER_PORT'] = str(free_port())
         # one node by contract (rendezvous on 127.0.0.1): RCCL's bootstrap socket stays on loopback too, whatever the
         # container's hostname resolves to; the data path is xGMI / shared memory either way
         os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
@@ -165,7 +197,9 @@ def main():
         n_local, n_global = hi - lo, cfg['n']
 
     X = device_planted_shard(n_local, d, k, seed=(0 if world == 1 else 1000 + rank), device=device)
-    mean = X.sum(dtype=torch.float64)
+    mean = torch.zeros((), dtype=torch.float64, device=device)
+    for lo_ in range(0, n_local, 100000):
+        mean += X[lo_:lo_ + 100000].sum(dtype=torch.float64)
     if world > 1:
         dist.all_reduce(mean)
     mean = float(mean) / (float(n_global) * d)
@@ -178,7 +212,6 @@ def main():
     W0 = (a * torch.rand(n_local, k, device=device, generator=gw, dtype=torch.float64)).cpu().numpy()
     torch.cuda.synchronize()
 
-    weighted = bool(cfg.get('weighted'))
     Mask = None
     if weighted:
         gm = torch.Generator(device=device)
@@ -186,12 +219,34 @@ def main():
         Mask = (torch.rand(n_local, d, device=device, generator=gm) < 0.05).to(torch.float32)
         X.mul_(Mask)
         torch.cuda.synchronize()
-    sparse = bool(cfg.get('sparse'))
     sdt = np.float32 if args.storage == 'f32' else np.float64
     es = 4 if args.storage == 'f32' else 8
-    eng, red, stream = make_device_shard(n_local, d, k, dtype=sdt, device_index=local_rank,
-                                         weighted='sparse' if sparse else weighted)
-    nnz = 0
+
+    # ---- the handle, and for row-sharded runs who owns the collective --------------------------------------------
+    collective, group, drv, red, stream = 'none', None, None, None, None
+    flavour = 'sparse' if sparse else weighted
+    if sharded and args.collective == 'library' and not rehearsal:
+        try:
+            group = RowGroup.rccl(n_local, device=local_rank)
+            collective = 'RCCL inside librri_hip.so: one ncclAllReduce per topic step enqueued by rri_sweep on the handle\'s stream'
+        except Exception as e:  # noqa: BLE001  (measurement robustness: say so in the line and use the caller-owned protocol)
+            group = None
+            collective = 'torch.distributed (library communicator unavailable: %s)' % str(e)[:200]
+    if sharded and group is None:
+        if rehearsal and args.collective == 'library':
+            group = RowGroup.over_torch(n_local)
+            collective = 'REHEARSAL: host-callback transport over gloo (all ranks on one GPU; not a measurement)'
+        else:
+            if collective == 'none':
+                collective = 'torch.distributed all_reduce per topic step from Python (caller-owned protocol)'
+    if group is not None:
+        eng = RRIEngine(n_local, d, k, dtype=sdt, weighted=flavour, device=local_rank)
+        eng.attach_group(group)
+    elif sharded:
+        eng, red, stream = make_device_shard(n_local, d, k, dtype=sdt, device_index=local_rank, weighted=flavour)
+    else:
+        eng = RRIEngine(n_local, d, k, dtype=sdt, weighted=flavour, device=local_rank, schedule=args.schedule)
+    nnz, t_up = 0, 0.0
     if sparse:
         import scipy.sparse as sp
         nz = Mask.nonzero()                                   # row-major order = CSR order
@@ -220,11 +275,12 @@ def main():
     flags = dict(t_row_sum=1.0, reset_topic_method=None) if weighted else {}
     eng.set_params(**flags)   # plain RRI: no constraints, default resets; WRRI: the RS-fit flags
     row_lo = rank * n_local if cfg['scaling'] == 'weak' else shard_rows(cfg['n'], world, rank)[0]
-    drv = ShardedRRI(eng, red, k, stream=stream, row_lo=row_lo, n_global=n_global) if sharded else None
+    if sharded and group is None:
+        drv = ShardedRRI(eng, red, k, stream=stream, row_lo=row_lo, n_global=n_global)
 
     def run(steps):
         if drv is None:
-            eng.sweep(steps)
+            eng.sweep(steps)          # one C call: the kernels (and, row-sharded, the all-reduces) of `steps` sweeps
         else:
             drv.sweep(steps)
 
@@ -250,16 +306,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
 
-    launches, pass_ms = eng.timing_read(3 if weighted else 0)
+    resid_sched = args.schedule == 'residual'
+    launches, pass_ms = eng.timing_read(3 if (weighted or resid_sched) else 0)
     n1, wcol_ms = eng.timing_read(1)
     n2, trow_ms = eng.timing_read(2)
     pass_avg_ms = pass_ms / max(launches, 1)
     # plain: one fused pass reads X once.  weighted: two passes per topic step over (E, M): B reads E and M, C reads
     # E and M and writes E = 5 fp32 arrays with a dense fp32 mask (SURVEY 8d's figure); the 0/1 mask of this workload
     # is bit-packed by the library (1/32 of an array per read), so the schedule ACTUALLY moves 3 + 2/32 arrays per
-    # topic step: the roofline line is priced on what is moved, never on the larger formula
+    # topic step: the roofline line is priced on what is moved, never on the larger formula.
+    # explicit-residual schedule: one read + one write of R per topic step (2 n d s)
     mask_packed = weighted and os.environ.get('RRI_MASK_BITS', '1') != '0'
-    arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else 1.0
+    arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else (2.0 if resid_sched else 1.0)
     bytes_per_launch = float(n_local) * d * es * arrays_per_launch
     if sparse:
         # per topic step and observed entry: pass B reads (uint16 offset, fp32 value) of the row copy = 6 B; pass C
@@ -270,6 +328,7 @@ def main():
     sweeps_per_s = args.steps / elapsed
     shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
     value = sweeps_per_s * shards
+    sweep_bytes = ((6.0 + 5.0 * es) * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es)
 
     out = {
         'metric': 'RRI sweeps/sec and achieved HBM GB/s on dense X (n x d, rank k)',
@@ -279,32 +338,42 @@ def main():
         'config': {'workload': cfg['name'] + (' per GPU (row shard), %d x %d global' % (n_global, d)
                                               if world > 1 and cfg['scaling'] == 'weak' else ''),
                    'n_global': n_global, 'n_per_gpu': n_local, 'd': d, 'k': k,
-                   'x_storage': '%s on the observed pattern (%d entries, CSR + CSC), upload %.2f s' % (args.storage, nnz, t_up) if sparse else '%s in HBM' % args.storage, 'arithmetic': 'float64 (W, T, all sums)', 'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
-                   'parallelism': 'row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step'
-                                  % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2))) if world > 1 else 'single GPU'},
+                   'x_storage': '%s on the observed pattern (%d entries, CSR + CSC), upload %.2f s' % (args.storage, nnz, t_up) if sparse else '%s in HBM' % args.storage,
+                   'arithmetic': ('float64 sums, W, T; the factor tables of the pattern-only passes are rounded to the storage type'
+                                  if sparse and args.storage == 'f32' else 'float64 (W, T, all sums)'),
+                   'flavour': 'WRRI (W_mat)' if weighted else 'plain RRI',
+                   'schedule': ('explicit residual: R <- R - dw t^T - w dt^T, one read-modify-write pass per topic step, R rebuilt '
+                                'once per sweep' if resid_sched else 'maintained masked residual, two passes per topic step' if weighted
+                                else 'Gram form: one fused read of X per topic step (row dots + next column sums)'),
+                   'parallelism': ('row-sharded, %d rank(s), 1 all-reduce of %d doubles per topic step; %s'
+                                   % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2)), collective)) if sharded else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                      'kernel': ('k_sp_blk<float,...> passes B (row copy: read) and C (row + column copies: read, write), '
                                 'averaged; %d observed entries' % nnz if sparse else
                                 'k_wpass<float,...> passes B (read E, mask) and C (read E, mask; write E), averaged; mask '
                                 + ('bit-packed' if mask_packed else 'fp32') if weighted
+                                else 'k_pass<float,Y,Z,UPD=2> (rank-one residual update R <- R - a b^T - a2 b2^T, read + write, fused '
+                                     'with the row dots and column sums of the new R)' if resid_sched
                                 else 'k_pass<float,Y,Z> (fused row-dot + column-sum pass over X)'),
                      'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},
         'sweep_level': {'global_sweeps_per_s': sweeps_per_s,
                         'timed_launch_samples': launches,
                         'survey_formula': ('26*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' if sparse
                                            else '4*k*n*d*4 B per sweep (dense fp32 mask, residual not rewritten)' if weighted
-                                           else '2*k*n*d*4 B per sweep (two BLAS2 passes per topic step)'),
-                        'algorithmic_GBps_2knd': ((6.0 + 5.0 * es) * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es) * sweeps_per_s / 1e9,
-                        'frac_of_8TBps_2knd': ((6.0 + 5.0 * es) * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es) * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
+                                           else '2*k*n*d*4 B per sweep (two BLAS2 passes per topic step, or one read + one write of R)'),
+                        'algorithmic_GBps_2knd': sweep_bytes * sweeps_per_s / 1e9,
+                        'frac_of_8TBps_2knd': sweep_bytes * sweeps_per_s / 1e9 / HBM_PEAK_GBPS,
                         'kernel_avg_ms': {'pass': pass_avg_ms, 'wcol': wcol_ms / max(n1, 1),
                                           'trow_chain_segment': trow_ms / max(n2, 1)}},
     }
 
-    # HBM bytes of the dominant kernel(s) from PMC counters collected by the same command under rocprofv3 --pmc
-    # (separate FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py).  gfx950: FETCH_SIZE counts half the bytes of
-    # a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section), hence 2 x FETCH + WRITE.
-    pmc_file = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic_%s.json' % args.config)
+    # HBM bytes of the dominant kernel(s): PMC counters collected by this command under rocprofv3 --pmc (separate
+    # FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py) -- a STATIC profile of the build whose source stamp it
+    # carries; a stamp that differs from the sources of this run is flagged.  gfx950: FETCH_SIZE counts half the bytes
+    # of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section), hence 2 x FETCH + WRITE.
+    pmc_tag = args.config + ('_residual' if resid_sched else '')
+    pmc_file = os.path.join(ROOT, 'profiles', '%s_pmc_hbm_traffic_%s.json' % (PROFILE_ROUND, pmc_tag))
     if os.path.exists(pmc_file):
         try:
             pm = json.load(open(pmc_file))
@@ -314,17 +383,24 @@ def main():
             elif weighted:  # passes B and C (the prologue variant runs 3 times per call: left out)
                 keys = [kk for kk in pm if 'k_wpass<float' in kk and pm[kk]['launches'] > 10]
                 per_launch = 0.5
+            elif resid_sched:
+                keys = [kk for kk in pm if 'k_pass<float, true, true, 2' in kk]
+                per_launch = 1.0
             else:
-                keys = [kk for kk in pm if 'k_pass<float, true, true, false' in kk]
+                keys = [kk for kk in pm if 'k_pass<float, true, true, 0' in kk]
                 per_launch = 1.0
             tot = sum(2.0 * pm[kk]['FETCH_SIZE_KB_avg'] + pm[kk]['WRITE_SIZE_KB_avg'] for kk in keys) * 1024.0
-            out['roofline']['traffic'] = tot * per_launch
-            out['roofline']['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same '
-                                                 'kernels and shape, profiles/%s; FETCH_SIZE doubled per the gfx950 '
-                                                 'correction' % os.path.basename(pmc_file))
+            if keys:
+                out['roofline']['traffic'] = tot * per_launch
+                stamp = pm.get('_source_stamp')
+                out['roofline']['traffic_source'] = (
+                    'static profile: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same kernels and shape, '
+                    'profiles/%s, kernel sources %s; FETCH_SIZE doubled per the gfx950 correction' % (os.path.basename(pmc_file), stamp))
+                out['roofline']['traffic_stale'] = stamp != source_stamp()
         except Exception:  # noqa: BLE001
             pass
 
+    thr = int(min(16, os.cpu_count() or 16))       # the box's CPU share for one GPU
     if rank == 0 and world == 1 and weighted and not args.no_cpu_baseline:
         rows = min(2000, n_local)
         if sparse:
@@ -333,16 +409,17 @@ def main():
             Xs, Ms = X[:rows].cpu().numpy().astype(np.float64), Mask[:rows].cpu().numpy().astype(np.float64)
         from oracle import rri_oracle as orc
         from threadpoolctl import threadpool_limits
-        thr = int(min(16, os.cpu_count() or 16))
         with threadpool_limits(limits=thr):
             t1 = time.perf_counter()
-            ref = orc.nmf(Xs, k, W_in=W0[:rows].copy(), T_in=T0.copy(), W_mat=Ms, max_iter=1, eps_stop=-1, **flags)
+            ref = orc.nmf(Xs, k, W_in=W0[:rows].copy(), T_in=T0.copy(), W_mat=Ms, max_iter=1, eps_stop=-1,
+                          compute_obj_each_iter=True, **flags)
             dt1 = time.perf_counter() - t1
         out['cpu_baseline'] = dict(value=(1.0 / dt1) * rows / float(n_local), unit='sweeps/s', cores=thr, kind='port',
-                                   sample='first %d of %d rows, 1 sweep (two n*d*k GEMMs per topic step), numpy float64 on %d '
-                                          'threads; sample rate %.4f sweeps/s scaled by %.4g' % (rows, n_local, thr, 1.0 / dt1, rows / float(n_local)))
-        from rri_nmf_amd.engine import RRIEngine
-        with RRIEngine(rows, d, k, dtype=np.float32, weighted='sparse' if sparse else True, device=local_rank) as e2:
+                                   sample='first %d of %d rows, 1 sweep (two n*d*k GEMMs per topic step, as the reference), numpy '
+                                          'float64 on %d threads; sample rate %.4f sweeps/s, the value is that rate times %.4g (rows '
+                                          'of the sample / rows of the workload; a full-size sweep of this flavour takes ~5 CPU-minutes)'
+                                          % (rows, n_local, thr, 1.0 / dt1, rows / float(n_local)))
+        with RRIEngine(rows, d, k, dtype=sdt, weighted='sparse' if sparse else True, device=local_rank) as e2:
             if sparse:
                 import scipy.sparse as sp
                 As = sp.csr_matrix(Ms)
@@ -352,23 +429,30 @@ def main():
                 e2.upload_X(Xs); e2.upload_mask(Ms)
             e2.set_W(W0[:rows]); e2.set_T(T0); e2.set_params(**flags)
             e2.sweep(1)
-            Wg, Tg = e2.get_W(), e2.get_T()
+            Wg, Tg, og = e2.get_W(), e2.get_T(), e2.objective()
         rec = lambda W_, T_: Ms * (W_ @ T_)
         out['parity_sample'] = {'sweeps': 1, 'rows': rows,
-                                'relfro_W': float(np.linalg.norm(Wg - ref['W']) / np.linalg.norm(ref['W'])),
-                                'relfro_T': float(np.linalg.norm(Tg - ref['T']) / np.linalg.norm(ref['T'])),
-                                'relfro_masked_WT': float(np.linalg.norm(rec(Wg, Tg) - rec(ref['W'], ref['T'])) / np.linalg.norm(rec(ref['W'], ref['T'])))}
+                                'relfro_W': relfro(Wg, ref['W']), 'relfro_T': relfro(Tg, ref['T']),
+                                'relfro_masked_WT': relfro(rec(Wg, Tg), rec(ref['W'], ref['T'])),
+                                'rel_objective': abs(og - ref['obj_history'][-1]) / abs(ref['obj_history'][-1]),
+                                'statement': 'the residual is stored in %s: parity of this flavour is stated on the objective and the '
+                                             'masked reconstruction M.(WT) (at full size from a random start the trajectory of W, T '
+                                             'amplifies a storage rounding of 6e-8 to percents while those two agree: '
+                                             'tests/test_full_size_gpu.py, DESIGN.md 7)' % args.storage}
         out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
     if rank == 0 and world == 1 and not weighted:
-        # the explicit rank-one residual update R <- R - a b^T (read + write, fused residual products)
+        # the explicit rank-one residual update R <- R - a b^T (read + write, fused residual products), with the handle's
+        # own factors W[:,0], T[0,:] as a, b (tests/test_residual_gpu.py checks the same kernel against numpy / torch)
         try:
             r1_ms = eng.bench_rank1_update(5)
             cp_ms = eng.bench_stream_copy(5)
-            out['rank1_update'] = {'bound': 'hbm', 'achieved': 2 * bytes_per_launch / (r1_ms * 1e-3) / 1e9,
+            rw_bytes = 2.0 * float(n_local) * d * es
+            out['rank1_update'] = {'bound': 'hbm', 'achieved': rw_bytes / (r1_ms * 1e-3) / 1e9,
                                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                                   'frac': 2 * bytes_per_launch / (r1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                   'bytes_per_launch': 2 * bytes_per_launch, 'avg_ms': r1_ms,
-                                   'stream_copy_GBps': 2 * bytes_per_launch / (cp_ms * 1e-3) / 1e9}
+                                   'frac': rw_bytes / (r1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   'bytes_per_launch': rw_bytes, 'avg_ms': r1_ms,
+                                   'kernel': 'k_pass<float,Y,Z,UPD=1>: R <- R - w_0 t_0^T on a scratch copy of X, row dots and column sums of the new R',
+                                   'stream_copy_GBps': rw_bytes / (cp_ms * 1e-3) / 1e9}
             # "report fraction of 8.0 and of [the achievable float4 copy]", here the copy measured in this run
             copy_gbps = out['rank1_update']['stream_copy_GBps']
             out['roofline']['frac_of_measured_copy'] = achieved / copy_gbps   # a read-only pass can exceed a read+write copy
@@ -376,37 +460,140 @@ def main():
             out['rank1_update']['frac_of_measured_copy'] = out['rank1_update']['achieved'] / copy_gbps
         except Exception as e:  # noqa: BLE001
             out['rank1_update'] = {'error': str(e)}
+        if not resid_sched and args.config in ('c3', 'c2', 'mid'):
+            # the whole explicit-residual schedule on the same X, start and sweeps: its rate, its kernel, and how far its
+            # factors are from the default schedule's after the same sweeps
+            try:
+                with RRIEngine(n_local, d, k, dtype=sdt, device=local_rank, schedule='residual') as e3:
+                    e3.bind_X_device(X.data_ptr(), X.stride(0))
+                    e3.set_W(W0), e3.set_T(T0), e3.set_params()
+                    e3.sweep(max(args.warmup, 1))
+                    e3.synchronize()
+                    e3.timing_enable(True, every=8)
+                    t3 = time.perf_counter()
+                    e3.sweep(args.steps)
+                    e3.synchronize()
+                    dt3 = time.perf_counter() - t3
+                    c3n, c3ms = e3.timing_read(3)
+                    Wr, Tr = e3.get_W(), e3.get_T()
+                Wd, Td = eng.get_W(), eng.get_T()
+                avg3 = c3ms / max(c3n, 1)
+                out['rank1_update']['schedule'] = {
+                    'what': 'RRIEngine(schedule=\'residual\'): every topic step is ONE rank-one residual update pass (k_pass UPD=2: '
+                            'R <- R - dw t^T - w dt^T, read + write) fused with R t and R^T w; R rebuilt once per sweep',
+                    'sweeps_per_s': args.steps / dt3, 'kernel_avg_ms': avg3,
+                    'achieved_GBps': rw_bytes / (avg3 * 1e-3) / 1e9 if c3n else None,
+                    'frac': rw_bytes / (avg3 * 1e-3) / 1e9 / HBM_PEAK_GBPS if c3n else None,
+                    'sweep_frac_of_8TBps_2knd': sweep_bytes * (args.steps / dt3) / 1e9 / HBM_PEAK_GBPS,
+                    'vs_default_schedule_after_%d_sweeps' % (args.warmup + args.steps): {'relfro_W': relfro(Wr, Wd), 'relfro_T': relfro(Tr, Td)}}
+            except Exception as e:  # noqa: BLE001
+                out['rank1_update']['schedule'] = {'error': str(e)}
         if not args.no_cpu_baseline:
-            rows = min(args.cpu_rows, n_local)
-            Xs = X[:rows].cpu().numpy()
-            cb, Wc, Tc, sens = cpu_baseline(Xs, W0[:rows], T0, n_local)
-            out['cpu_baseline'] = cb
-            # parity in the same run: the device path on the same sample, equal sweeps (1 + 2)
-            from rri_nmf_amd.engine import RRIEngine
-            with RRIEngine(rows, d, k, dtype=np.float32, device=local_rank) as e2:
-                e2.upload_X(Xs)                      # warm-up (allocation)
-                tu = time.perf_counter()
-                e2.upload_X(Xs)
-                tu = time.perf_counter() - tu
-                h2d = Xs.nbytes / tu / 1e9
-                out['pcie_inclusive'] = {
-                    'h2d_GBps_pageable': h2d, 'x_upload_ms': 1e3 * bytes_per_launch / (h2d * 1e9),
-                    'note': 'rri_upload_X of the %d-row sample from pageable host memory; uploading the whole X once '
-                            'costs x_upload_ms = %.1f sweeps; never part of `value`'
-                            % (rows, bytes_per_launch / (h2d * 1e9) * sweeps_per_s)}
-                e2.set_W(W0[:rows])
-                e2.set_T(T0)
-                e2.set_params()
-                e2.sweep(3)
-                Wg, Tg = e2.get_W(), e2.get_T()
-            out['parity_sample'] = {
-                'sweeps': 3, 'rows': rows,
-                'relfro_W': float(np.linalg.norm(Wg - Wc) / np.linalg.norm(Wc)),
-                'relfro_T': float(np.linalg.norm(Tg - Tc) / np.linalg.norm(Tc)),
-                'relfro_WT': float(np.linalg.norm(Wg @ Tg - Wc @ Tc) / np.linalg.norm(Wc @ Tc)),
-                'reference_self_sensitivity': sens}
-            out['gpu_over_cpu'] = value / cb['value'] if cb['value'] else None
+            full = args.config in ('c2', 'c3', 'mid')
+            rows = args.cpu_rows or (n_local if full else min(100000, n_local))
+            rows = min(rows, n_local)
+            times, facs, X64 = cpu_plain(X, W0, T0, rows, args.cpu_sweeps, thr, n_local)
+            rate = len(times) / sum(times)
+            out['cpu_baseline'] = dict(
+                value=rate * rows / float(n_local), unit='sweeps/s', cores=thr, kind='port',
+                sample=('ALL %d rows of the same X' % rows if rows == n_local else 'first %d of %d rows of the same X (rate times %.4g)'
+                        % (rows, n_local, rows / float(n_local))) +
+                       ', %d timed sweeps (%s s), numpy float64 + OpenBLAS on %d threads (%d host cpus), oracle/rri_oracle.py'
+                       % (len(times), ', '.join('%.2f' % t for t in times), thr, os.cpu_count() or 0))
+            # one BLAS thread, on a bounded row sample (a full-size sweep on one thread takes minutes)
+            rows1 = min(rows, 10000)
+            t1s, _, _ = cpu_plain(X, W0, T0, rows1, 1, 1, n_local, want_factors=False)
+            out['cpu_baseline']['one_thread'] = dict(
+                value=(1.0 / t1s[0]) * rows1 / float(n_local), cores=1,
+                sample='first %d rows, 1 sweep on 1 BLAS thread: %.3f sweeps/s on the sample, times %.4g' % (rows1, 1.0 / t1s[0], rows1 / float(n_local)))
+            # parity in the same run: the device path on the same rows, same start, after 1 .. cpu_sweeps sweeps
+            par = {'rows': rows, 'what': 'device (fp32 X in HBM, float64 arithmetic) vs the CPU run above on the same rows and start'}
+            with RRIEngine(rows, d, k, dtype=sdt, device=local_rank, schedule=args.schedule) as e2:
+                Xr = X[:rows]
+                e2.bind_X_device(Xr.data_ptr(), Xr.stride(0))
+                e2.set_W(W0[:rows]), e2.set_T(T0), e2.set_params()
+                srows = min(rows, 2000)
+                for s_, (Wc, Tc) in enumerate(facs, 1):
+                    e2.sweep(1)
+                    Wg, Tg = e2.get_W(), e2.get_T()
+                    par['after_%d_sweeps' % s_] = {'relfro_W': relfro(Wg, Wc), 'relfro_T': relfro(Tg, Tc),
+                                                   'relfro_WT_first_%d_rows' % srows: relfro(Wg[:srows] @ Tg, Wc[:srows] @ Tc)}
+            last = par['after_%d_sweeps' % len(facs)]
+            par.update(sweeps=len(facs), relfro_W=last['relfro_W'], relfro_T=last['relfro_T'])
+            # control: the CPU restatement against itself with every entry of W0 moved to the next double -- the
+            # iteration's own sensitivity, which bounds what any two implementations (or two BLAS builds) can show
+            from oracle import rri_oracle as orc
+            from threadpoolctl import threadpool_limits
+            crow = min(rows, 20000)
+            with threadpool_limits(limits=thr):
+                Wa, Ta = W0[:crow].astype(np.float64).copy(), T0.astype(np.float64).copy()
+                Wb, Tb = np.nextafter(Wa, np.inf), Ta.copy()
+                orc.plain_sweeps(X64[:crow], Wa, Ta, len(facs))
+                orc.plain_sweeps(X64[:crow], Wb, Tb, len(facs))
+            par['reference_self_sensitivity'] = {'rows': crow, 'sweeps': len(facs), 'relfro_W': relfro(Wb, Wa), 'relfro_T': relfro(Tb, Ta),
+                                                 'what': 'CPU restatement vs itself, every entry of W0 one ulp up (np.nextafter), first %d rows' % crow}
+            del X64
+            out['parity_sample'] = par
+            if args.config == 'c3' and not resid_sched:
+                # PCIe-inclusive: bringing X to the device once from pageable host memory (never part of `value`)
+                Xh = X[:10000].cpu().numpy()
+                with RRIEngine(10000, d, k, dtype=np.float32, device=local_rank) as e4:
+                    e4.upload_X(Xh)
+                    tu = time.perf_counter()
+                    e4.upload_X(Xh)
+                    tu = time.perf_counter() - tu
+                h2d = Xh.nbytes / tu / 1e9
+                out['pcie_inclusive'] = {'h2d_GBps_pageable': h2d, 'x_upload_ms': 1e3 * bytes_per_launch / (h2d * 1e9),
+                                         'note': 'rri_upload_X of a 10000-row sample from pageable host memory; uploading the whole X once '
+                                                 'costs x_upload_ms = %.1f sweeps; never part of `value`' % (bytes_per_launch / (h2d * 1e9) * sweeps_per_s)}
+            out['gpu_over_cpu'] = value / out['cpu_baseline']['value'] if out['cpu_baseline']['value'] else None
+    if sharded and world > 1 and not weighted and not args.no_cpu_baseline:
+        # N > 1: (i) the CPU restatement on rank 0's shard as a stand-alone problem (same work per sweep as the shard's
+        # share); (ii) parity THROUGH the N-rank path: a small global problem (20000 x d, same k), row-sharded over the
+        # same ranks and collective, against the CPU oracle on all its rows -- every rank takes part, rank 0 reports
+        rows_s = 20000
+        Xs_dev = device_planted_shard(rows_s, d, k, seed=77, device=device)          # the same matrix on every rank
+        lo_s, hi_s = shard_rows(rows_s, world, rank)
+        as_ = (float(Xs_dev.sum(dtype=torch.float64)) / (float(rows_s) * d) / k) ** 0.5
+        gs = torch.Generator(device=device)
+        gs.manual_seed(5)
+        Ws0 = (as_ * torch.rand(rows_s, k, device=device, generator=gs, dtype=torch.float64)).cpu().numpy()
+        Ts0 = (as_ * torch.rand(k, d, device=device, generator=gs, dtype=torch.float64)).cpu().numpy()
+        torch.cuda.synchronize()
+        Xs_loc = Xs_dev[lo_s:hi_s].contiguous()
+        torch.cuda.synchronize()
+        if group is not None:
+            g2 = RowGroup(group._comm, rank, world, [shard_rows(rows_s, world, r)[1] - shard_rows(rows_s, world, r)[0] for r in range(world)])
+            e5 = RRIEngine(hi_s - lo_s, d, k, dtype=np.float32, device=local_rank)
+            e5.attach_group(g2)
+            e5.bind_X_device(Xs_loc.data_ptr(), Xs_loc.stride(0))
+            e5.set_W(Ws0[lo_s:hi_s]), e5.set_T(Ts0), e5.set_params()
+            e5.sweep(2)
+        else:
+            e5, red5, st5 = make_device_shard(hi_s - lo_s, d, k, dtype=np.float32, device_index=local_rank)
+            e5.bind_X_device(Xs_loc.data_ptr(), Xs_loc.stride(0))
+            e5.set_W(Ws0[lo_s:hi_s]), e5.set_T(Ts0), e5.set_params()
+            ShardedRRI(e5, red5, k, stream=st5, row_lo=lo_s, n_global=rows_s).sweep(2)
+        Wg5, Tg5 = e5.get_W(), e5.get_T()
+        e5.close()
+        if rank == 0:
+            times, facs, _ = cpu_plain(Xs_dev, Ws0, Ts0, rows_s, 2, thr, rows_s)
+            Wc, Tc = facs[-1]
+            out['parity_sample'] = {'what': 'a %d x %d, k=%d problem row-sharded over the same %d ranks and collective, rank 0\'s rows of W and '
+                                            'the replicated T against the CPU oracle on all rows' % (rows_s, d, k, world),
+                                    'sweeps': 2, 'rows': rows_s, 'relfro_W': relfro(Wg5, Wc[lo_s:hi_s]), 'relfro_T': relfro(Tg5, Tc)}
+            rows = min(n_local, 100000)
+            times, _, _ = cpu_plain(X, W0, T0, rows, 1, thr, n_local, want_factors=False)
+            shard_rate = (1.0 / times[0]) * rows / float(n_local)     # sweeps/s of ONE n_local-row shard on these host cores
+            out['cpu_baseline'] = dict(value=shard_rate * (1.0 if cfg['scaling'] == 'weak' else 1.0 / world), unit='sweeps/s', cores=thr, kind='port',
+                                       sample='rank 0\'s shard as a stand-alone problem: first %d of its %d rows, 1 timed sweep (%.2f s), numpy float64 on %d '
+                                              'threads; in the unit of `value` ONE host like this one does %s' % (
+                                                  rows, n_local, times[0], thr, 'this many shard-sweeps per second (the job has %d shards)' % world
+                                                  if cfg['scaling'] == 'weak' else 'the whole %d-row problem at this rate (shard rate / %d)' % (n_global, world)))
+            out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
     eng.close()
+    if group is not None:
+        group.close()
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -41,7 +41,9 @@ extern "C" {
 /* largest rank k a handle takes */
 #define RRI_MAX_K 1024
 
-typedef struct rri_ctx rri_ctx; /* opaque */
+typedef struct rri_ctx rri_ctx;   /* opaque: one nmf() call (or one row shard of it) on one GPU */
+typedef struct rri_comm rri_comm; /* opaque: the communicator of a row-sharded run, one per process */
+#define RRI_COMM_ID_BYTES 128     /* sizeof(ncclUniqueId) */
 
 typedef int32_t rri_status;
 enum {
@@ -52,11 +54,13 @@ enum {
     RRI_ERR_UNSUPPORTED = -3,   /* option not available on the device path                  */
     RRI_ERR_UNBOUNDED = -4,     /* qf_min: minimum objective is unbounded (optimization.py:66-67,76-77) */
     RRI_ERR_W_COL_ZERO = -5,    /* assert sum(W[:,t]) > 0 failed (nmf.py:476)               */
-    RRI_ERR_NOT_IMPLEMENTED = -6 /* qf_min: c<=0 with s not in {None,1.0} (optimization.py:72-73) */
+    RRI_ERR_NOT_IMPLEMENTED = -6, /* qf_min: c<=0 with s not in {None,1.0} (optimization.py:72-73) */
+    RRI_ERR_COMM = -7            /* a collective (RCCL, or the caller's transport) failed                   */
 };
 
 enum { RRI_F32 = 0, RRI_F64 = 1 };   /* storage type of X, mask, residual in HBM (arithmetic is float64) */
-enum { RRI_UNWEIGHTED = 0, RRI_WEIGHTED_DENSE = 1, RRI_WEIGHTED_SPARSE = 2 };   /* rri_create's `weighted` */
+/* rri_create's `weighted`: the flavour of the handle */
+enum { RRI_UNWEIGHTED = 0, RRI_WEIGHTED_DENSE = 1, RRI_WEIGHTED_SPARSE = 2, RRI_UNWEIGHTED_RESIDUAL = 3 };
 enum { RRI_RESET_NONE = 0, RRI_RESET_MAX_RESID_DOCUMENT = 1, RRI_RESET_RANDOM = 2 };
 enum { RRI_EVENT_NONE = 0, RRI_EVENT_RESET_T = 1, RRI_EVENT_RESET_W = 2 };
 
@@ -90,6 +94,10 @@ uint32_t   rri_abi_version(void);
 /* dtype: RRI_F32 / RRI_F64.  weighted: RRI_UNWEIGHTED; RRI_WEIGHTED_DENSE reserves the mask and masked-residual
  * buffers of the elementwise-weighted flavour (WRRI, nmf.py:687-701,735-746) as dense n x d arrays;
  * RRI_WEIGHTED_SPARSE keeps that flavour on a 0/1 observation pattern only (rri_upload_observed_csr).
+ * RRI_UNWEIGHTED_RESIDUAL is the unweighted flavour on the EXPLICIT residual R = X - W T (kept in HBM beside X): every
+ * topic step is one rank-one residual update pass R <- R -+ v u^T fused with the residual products R t / R^T w of
+ * nmf.py:670-676,728-734 (SURVEY 8a "explicit-residual variant"; k >= 2, both halves free), 2 n d bytes per step
+ * where the default Gram-form schedule (RRI_UNWEIGHTED) reads X once.  Same results to rounding.
  * device: HIP device ordinal.  stream: hipStream_t to run on, or NULL for an own stream. */
 rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dtype,
                       int32_t weighted, int32_t device, void* stream);
@@ -147,6 +155,18 @@ rri_status rri_skip_reset(rri_ctx* ctx);
 rri_status rri_update_T_row(rri_ctx* ctx, int32_t t);   /* nmf.py:417-458 */
 rri_status rri_update_W_col(rri_ctx* ctx, int32_t t);   /* nmf.py:460-476 */
 
+/* ---- the explicit residual (RRI_UNWEIGHTED_RESIDUAL handles) ---------------------- */
+/* R = X - W T for the handle's current factors (the products of nmf.py:670-676 / 728-734 are taken on it). */
+rri_status rri_residual_rebuild(rri_ctx* ctx);
+/* The outer-product residual update as an operation of its own:
+ *     R <- R - a b^T [- a2 b2^T]      (a, a2: n doubles; b, b2: d doubles; a2 = b2 = NULL for one term)
+ * fused with y = R_new trow (n, nmf.py:729) and z = R_new^T wcol (d, nmf.py:672) of the updated residual, all host
+ * vectors, float64 arithmetic, R rounded to the handle's storage type when stored.  y_out / z_out may be NULL.
+ * The stored R then no longer belongs to the handle's (W, T): the next sweep rebuilds it. */
+rri_status rri_residual_update(rri_ctx* ctx, const double* a, const double* b, const double* a2, const double* b2,
+                               const double* trow, const double* wcol, double* y_out, double* z_out);
+rri_status rri_get_residual(rri_ctx* ctx, void* host, int64_t ld, int32_t host_dtype);   /* n*d, as stored */
+
 /* ---- around the loop ------------------------------------------------------------ */
 /* Row-wise simplex projection of W (proj_mat_to_simplex, matrixops.py:72-100; final
  * projection nmf.py:519-529).  s_vec == NULL: every row to the scalar s; else n doubles. */
@@ -180,7 +200,41 @@ rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 rri_status rri_column_positive_counts(rri_ctx* ctx, double* df_out);
 rri_status rri_scale_X(rri_ctx* ctx, const double* col_scale, int32_t normalize_rows);
 
-/* ---- row-sharded multi-GPU (one process per GPU; the caller owns the collective) ---- */
+/* ---- row-sharded multi-GPU inside the library (one process per GPU; SURVEY 8b "sharded by row block internally",
+ *      8e).  The reference has one call for the whole X (nmf.py:98-108); here every rank creates a handle for its row
+ *      block [row_offset, row_offset + n) of the n_global-row problem (W rows alike, T replicated), attaches the
+ *      process's communicator, and then calls the SAME entry points -- rri_sweep, rri_resume, rri_update_*,
+ *      rri_objective, rri_apply_reset_* -- collectively, with the same arguments on every rank.  The one cross-row
+ *      reduction of a topic step ([w_t^T X | w_t^T W | ||w_t||^2 | sum W[:,t-1]], or [numerator | denominator] of the
+ *      weighted flavour) is all-reduced by RCCL over xGMI on the handle's stream between two kernels: a sweep is ONE
+ *      call with no host work per topic.  Every decision (reset events, the assert of nmf.py:476, unbounded cases)
+ *      is taken from all-reduced or replicated values, so all ranks return the same status.
+ *      All flavours and flags of rri_sweep (fixed halves, k = 1, weighted, pattern-only) except RRI_UNWEIGHTED_RESIDUAL. */
+/* rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks by any channel the host program has */
+rri_status rri_comm_unique_id(uint8_t* id_out /* RRI_COMM_ID_BYTES */);
+/* RCCL communicator of `world` ranks; this process is `rank` and drives HIP device `device`.  Collective. */
+rri_status rri_comm_create(rri_comm** out, const uint8_t* id, int32_t rank, int32_t world, int32_t device);
+/* The same protocol over the CALLER's transport (tests with several ranks on one GPU; hosts without RCCL): the
+ * library drains the stream, hands `count` doubles in host memory to the function and copies the result back.
+ * Each function returns 0 on success.  allreduce: sum in place over the ranks; allgather: recv = world x count;
+ * broadcast: from `root` in place. */
+typedef int32_t (*rri_allreduce_fn)(void* user, double* buf, int64_t count);
+typedef int32_t (*rri_allgather_fn)(void* user, const double* send, int64_t count, double* recv);
+typedef int32_t (*rri_broadcast_fn)(void* user, double* buf, int64_t count, int32_t root);
+rri_status rri_comm_create_host(rri_comm** out, int32_t rank, int32_t world, rri_allreduce_fn allreduce,
+                                rri_allgather_fn allgather, rri_broadcast_fn broadcast, void* user);
+rri_status rri_comm_destroy(rri_comm* comm);     /* after every handle it was attached to is destroyed */
+/* comm == NULL detaches.  row_offset: global index of the handle's first row. */
+rri_status rri_attach_comm(rri_ctx* ctx, rri_comm* comm, int64_t row_offset, int64_t n_global);
+/* small host-side collectives for the host driver (the vectors of a 'random' reset drawn on rank 0, nmf.py:778-783;
+ * stop decisions): no-ops on a handle without a communicator.  allreduce_sum: at most 8 values. */
+rri_status rri_comm_broadcast(rri_ctx* ctx, double* host, int64_t count, int32_t root);
+rri_status rri_comm_allreduce_sum(rri_ctx* ctx, double* host, int64_t count);
+rri_status rri_comm_stats(rri_ctx* ctx, int32_t* rank, int32_t* world, int64_t* allreduce_calls);
+
+/* ---- row-sharded stepping with the collective in the CALLER's hands (the protocol the calls above run inside
+ *      rri_sweep; kept for hosts that own their collectives and for the Gaussian mechanism, whose noise enters at the
+ *      same point) ---- */
 /* A topic step splits at the one cross-row reduction it needs.  rri_topic_reduce_local
  * leaves this rank's partial sums [w_t^T X (LD) | RRI_GRAM_SLICES x (w_t^T W (k), ||w_t||^2, sum W[:,t-1])]
  * (LD = d rounded up to the 16-byte row stride; a Gram entry is the sum of its slices)
@@ -222,7 +276,7 @@ rri_status rri_timing_enable(rri_ctx* ctx, int32_t on);
 rri_status rri_timing_read(rri_ctx* ctx, int32_t kernel_id, int64_t* launches, double* total_ms);
 rri_status rri_synchronize(rri_ctx* ctx);
 /* Stand-alone kernels for roofline measurement (bench.py): R <- R - a b^T fused with the
- * next residual products, on a scratch residual of the handle's shape. */
+ * next residual products, on a scratch copy of X, with the handle's own W[:,0], T[0,:] as factors. */
 rri_status rri_bench_rank1_update(rri_ctx* ctx, int32_t reps, double* avg_ms);
 rri_status rri_bench_stream_copy(rri_ctx* ctx, int32_t reps, double* avg_ms);
 

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get('RRI_HIP_LIB', os.path.join(_PKG, 'lib', 'librri_hip.s
 RRI_GRAM_SLICES = 8     # include/rri_hip.h
 RRI_OK, RRI_PAUSED = 0, 1
 RRI_ERR_INVALID, RRI_ERR_HIP, RRI_ERR_UNSUPPORTED = -1, -2, -3
-RRI_ERR_UNBOUNDED, RRI_ERR_W_COL_ZERO, RRI_ERR_NOT_IMPLEMENTED = -4, -5, -6
+RRI_ERR_UNBOUNDED, RRI_ERR_W_COL_ZERO, RRI_ERR_NOT_IMPLEMENTED, RRI_ERR_COMM = -4, -5, -6, -7
+RRI_COMM_ID_BYTES = 128
 RRI_F32, RRI_F64 = 0, 1
 RESET_NONE, RESET_MAX_RESID_DOCUMENT, RESET_RANDOM = 0, 1, 2
 EVENT_NONE, EVENT_RESET_T, EVENT_RESET_W = 0, 1, 2
@@ -37,6 +38,10 @@ class Event(C.Structure):
 
 _P = C.c_void_p
 _I32, _I64, _D = C.c_int32, C.c_int64, C.c_double
+# transport callbacks of rri_comm_create_host
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double))
+BROADCAST_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int32)
 # name -> (restype, argtypes): every symbol include/rri_hip.h declares
 PROTOTYPES = {
     'rri_abi_version': (C.c_uint32, []),
@@ -67,12 +72,23 @@ PROTOTYPES = {
     'rri_objective': (_I32, [_P, C.POINTER(_D)]),
     'rri_argmax_rows': (_I32, [_P, C.POINTER(_I32)]),
     'rri_masked_rmse': (_I32, [_P, C.POINTER(_I64), C.POINTER(_D), _I64, _D, _D, C.POINTER(_D)]),
+    'rri_residual_rebuild': (_I32, [_P]),
+    'rri_residual_update': (_I32, [_P] + [C.POINTER(_D)] * 8),
+    'rri_get_residual': (_I32, [_P, _P, _I64, _I32]),
     'rri_snapshot': (_I32, [_P]),
     'rri_rollback': (_I32, [_P]),
     'rri_X_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
     'rri_Xt_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
     'rri_column_positive_counts': (_I32, [_P, C.POINTER(_D)]),
     'rri_scale_X': (_I32, [_P, C.POINTER(_D), _I32]),
+    'rri_comm_unique_id': (_I32, [C.POINTER(C.c_uint8)]),
+    'rri_comm_create': (_I32, [C.POINTER(_P), C.POINTER(C.c_uint8), _I32, _I32, _I32]),
+    'rri_comm_create_host': (_I32, [C.POINTER(_P), _I32, _I32, ALLREDUCE_FN, ALLGATHER_FN, BROADCAST_FN, _P]),
+    'rri_comm_destroy': (_I32, [_P]),
+    'rri_attach_comm': (_I32, [_P, _P, _I64, _I64]),
+    'rri_comm_broadcast': (_I32, [_P, C.POINTER(_D), _I64, _I32]),
+    'rri_comm_allreduce_sum': (_I32, [_P, C.POINTER(_D), _I64]),
+    'rri_comm_stats': (_I32, [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64)]),
     'rri_reduce_buffer': (_I32, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     'rri_bind_reduce_buffer': (_I32, [_P, _P, _I64]),
     'rri_reduce_read': (_I32, [_P, C.POINTER(C.c_double), _I64]),
@@ -114,6 +130,24 @@ def _share_hip_runtime_with_torch():
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:  # noqa: BLE001  (best effort: the system runtime is the fallback)
+        pass
+
+
+def share_rccl_with_torch():
+    """The RCCL the library resolves at run time must be the one bound to the HIP runtime in use: when torch is
+    installed that is torch's bundled librccl.so (same reasoning as above).  Making it global lets the library's
+    dlsym(RTLD_DEFAULT, "ncclAllReduce") find it; without torch the library opens the system librccl.so.1 itself."""
+    if os.environ.get('RRI_HIP_OWN_RUNTIME', '0') == '1' or os.environ.get('RRI_RCCL_LIB'):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'librccl.so')
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001  (best effort: the library falls back to the system RCCL)
         pass
 
 

@@ -40,6 +40,7 @@ def build(force=False, report=False):
            '-I' + os.path.join(ROOT, 'include'), SRC, '-o', LIB]
     if report:
         cmd.append('-Rpass-analysis=kernel-resource-usage')
+    print(' '.join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout)

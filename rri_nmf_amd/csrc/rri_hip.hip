@@ -14,6 +14,9 @@
 //   Gpart nwb x (k+2)      per-block partial Gram row / norm / column sum (float64)
 //   red   LD + 8 (k+2)     reduced [w^T X | 8 slice sums of (w^T W, ||w||^2, sum W[:,t-1])]  (all-reduce payload)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the symbols are resolved at run time (rccl_api below), so the
+                         // library has no link-time dependency on RCCL and loads on a box without it
 
 #include <algorithm>
 #include <cstdarg>
@@ -63,6 +66,67 @@ struct TimedLaunch {
 
 }  // namespace
 
+// ---- communicator of a row-sharded run (one process per GPU) ---------------------------------------------------
+// RCCL entry points, looked up in the process (a host program that already carries an RCCL -- PyTorch-ROCm ships its
+// own, bound to its own HIP runtime -- must be the one used: two HIP runtimes in one process do not share streams) and
+// only then in librccl.so.1.  RRI_RCCL_LIB names another file.
+namespace {
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string err;
+};
+RcclApi load_rccl() {
+    RcclApi a;
+    void* h = nullptr;
+    auto resolve = [&](void* from) {
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(from, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(from, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(from, "ncclCommDestroy");
+        a.AllReduce = (decltype(a.AllReduce))dlsym(from, "ncclAllReduce");
+        a.AllGather = (decltype(a.AllGather))dlsym(from, "ncclAllGather");
+        a.Broadcast = (decltype(a.Broadcast))dlsym(from, "ncclBroadcast");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(from, "ncclGetErrorString");
+        return a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.AllGather && a.Broadcast &&
+               a.GetErrorString;
+    };
+    if (const char* e = getenv("RRI_RCCL_LIB")) {
+        h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        if (h && resolve(h)) { a.ok = true; return a; }
+        a.err = std::string("RRI_RCCL_LIB=") + e + " could not be used";
+        return a;
+    }
+    if (resolve(RTLD_DEFAULT)) { a.ok = true; return a; }
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h && resolve(h)) { a.ok = true; return a; }
+    }
+    a.err = "RCCL not found (no ncclAllReduce in the process, no librccl.so.1)";
+    return a;
+}
+RcclApi& rccl_api() {
+    static RcclApi api = load_rccl();
+    return api;
+}
+}  // namespace
+
+struct rri_comm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t nccl = nullptr;                 // RCCL transport (xGMI), or
+    rri_allreduce_fn h_allreduce = nullptr;    // host-callback transport (tests: several ranks on one GPU)
+    rri_allgather_fn h_allgather = nullptr;
+    rri_broadcast_fn h_broadcast = nullptr;
+    void* user = nullptr;
+    std::vector<double> hbuf, hbuf2;           // host staging of the callback transport
+    long n_allreduce = 0;
+};
+
 struct rri_ctx {
     i64 n = 0, d = 0, LD = 0;
     int k = 0, dtype = RRI_F32, weighted = 0, device = 0;
@@ -106,6 +170,12 @@ struct rri_ctx {
     } sp[2];
     bool resid_fresh = false;   // weighted: E was rebuilt and no half step has run since
     bool dt_pending = false;    // weighted: dtv holds a T-row change that E does not contain yet
+    // explicit-residual schedule of the unweighted flavour (RRI_UNWEIGHTED_RESIDUAL): R = X - W T lives in E and takes
+    // the two rank-one terms of a topic step inside the pass of the next one
+    bool explicit_resid = false;
+    bool dw_pending = false;    // dwv holds a W-column change (of topic dw_topic) that R does not contain yet
+    int dw_topic = 0;
+    double* told = nullptr;     // T[t,:] before its last update (dt = T[t,:] - told while dt_pending)
     double *Gpart = nullptr, *tpart = nullptr, *rowobj = nullptr, *rowpos = nullptr, *normpart = nullptr;
     double *dtmp = nullptr;  // small double scratch (device): [0] sum, ...
     double* objbuf = nullptr;   // W^T W | T T^T | cross terms of the objective assembled after a sweep
@@ -151,6 +221,14 @@ struct rri_ctx {
     bool skip_row_finish = false;  // the resumed W half must not re-run the T-row checks (stale partial sums)
     int nwb256 = 1;
 
+    // row-sharded run: this handle holds rows [row_offset, row_offset + n) of an n_global-row problem and every
+    // cross-row sum of the schedule is all-reduced over `comm` on the handle's stream (rri_attach_comm)
+    rri_comm* comm = nullptr;
+    i64 row_offset = 0, n_global = 0;
+    double* ctail = nullptr;   // 8 doubles (device): small collectives (column verdicts, objective parts)
+    double* cand = nullptr;    // 2 * world doubles (device): candidates of the max-residual reset
+    rri_status comm_status = RRI_OK;   // first failure of a collective inside an enqueued sequence
+
     int timing = 0;            // 0 off, N > 0: time every N-th launch of each kernel id
     long timing_seq[4] = {0, 0, 0, 0};
     std::vector<TimedLaunch> timed[4];
@@ -184,6 +262,80 @@ rri_status fail(rri_ctx* c, rri_status code, const char* fmt, ...) {
     if (!(c)) return RRI_ERR_INVALID
 
 i64 round_up(i64 a, i64 b) { return (a + b - 1) / b * b; }
+
+// ---- collectives of a row-sharded handle: all on the handle's stream --------------------------------------------
+// RCCL: enqueued like a kernel (no host synchronisation).  Host-callback transport: the stream is drained, the
+// buffer goes through host memory and the caller's function (tests with several ranks on one GPU).
+void comm_fail(rri_ctx* c, rri_status code, const char* what, const char* detail) {
+    if (c->comm_status == RRI_OK) {
+        c->comm_status = code;
+        c->err = std::string("collective failed: ") + what + ": " + (detail ? detail : "?");
+    }
+}
+void comm_allreduce(rri_ctx* c, double* dev, i64 count) {
+    rri_comm* m = c->comm;
+    if (!m || c->comm_status != RRI_OK) return;
+    m->n_allreduce += 1;
+    if (m->nccl) {
+        ncclResult_t r = rccl_api().AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, m->nccl, c->stream);
+        if (r != ncclSuccess) comm_fail(c, RRI_ERR_COMM, "ncclAllReduce", rccl_api().GetErrorString(r));
+        return;
+    }
+    m->hbuf.resize((size_t)count);
+    hipError_t e = hipMemcpyAsync(m->hbuf.data(), dev, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { comm_fail(c, RRI_ERR_HIP, "staging", hipGetErrorString(e)); return; }
+    if (m->h_allreduce(m->user, m->hbuf.data(), count) != 0) { comm_fail(c, RRI_ERR_COMM, "all-reduce callback", "non-zero return"); return; }
+    e = hipMemcpyAsync(dev, m->hbuf.data(), (size_t)count * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // hbuf is reused by the next collective
+    if (e != hipSuccess) comm_fail(c, RRI_ERR_HIP, "staging", hipGetErrorString(e));
+}
+void comm_allgather(rri_ctx* c, const double* dev_send, i64 count, double* dev_recv) {
+    rri_comm* m = c->comm;
+    if (!m || c->comm_status != RRI_OK) return;
+    if (m->nccl) {
+        ncclResult_t r = rccl_api().AllGather(dev_send, dev_recv, (size_t)count, ncclDouble, m->nccl, c->stream);
+        if (r != ncclSuccess) comm_fail(c, RRI_ERR_COMM, "ncclAllGather", rccl_api().GetErrorString(r));
+        return;
+    }
+    m->hbuf.resize((size_t)count);
+    m->hbuf2.resize((size_t)count * m->world);
+    hipError_t e = hipMemcpyAsync(m->hbuf.data(), dev_send, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { comm_fail(c, RRI_ERR_HIP, "staging", hipGetErrorString(e)); return; }
+    if (m->h_allgather(m->user, m->hbuf.data(), count, m->hbuf2.data()) != 0) { comm_fail(c, RRI_ERR_COMM, "all-gather callback", "non-zero return"); return; }
+    e = hipMemcpyAsync(dev_recv, m->hbuf2.data(), (size_t)count * m->world * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) comm_fail(c, RRI_ERR_HIP, "staging", hipGetErrorString(e));
+}
+void comm_broadcast(rri_ctx* c, double* dev, i64 count, int root) {
+    rri_comm* m = c->comm;
+    if (!m || c->comm_status != RRI_OK) return;
+    if (m->nccl) {
+        ncclResult_t r = rccl_api().Broadcast(dev, dev, (size_t)count, ncclDouble, root, m->nccl, c->stream);
+        if (r != ncclSuccess) comm_fail(c, RRI_ERR_COMM, "ncclBroadcast", rccl_api().GetErrorString(r));
+        return;
+    }
+    m->hbuf.resize((size_t)count);
+    hipError_t e = hipMemcpyAsync(m->hbuf.data(), dev, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { comm_fail(c, RRI_ERR_HIP, "staging", hipGetErrorString(e)); return; }
+    if (m->h_broadcast(m->user, m->hbuf.data(), count, root) != 0) { comm_fail(c, RRI_ERR_COMM, "broadcast callback", "non-zero return"); return; }
+    e = hipMemcpyAsync(dev, m->hbuf.data(), (size_t)count * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) comm_fail(c, RRI_ERR_HIP, "staging", hipGetErrorString(e));
+}
+// `count` host doubles summed over the ranks in place (objective parts, decisions of the host driver)
+rri_status comm_allreduce_host(rri_ctx* c, double* host, i64 count) {
+    if (!c->comm) return RRI_OK;
+    if (count > 8) return fail(c, RRI_ERR_INVALID, "host all-reduce takes at most 8 values");
+    HIPCHK(c, hipMemcpyAsync(c->ctail, host, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    comm_allreduce(c, c->ctail, count);
+    HIPCHK(c, hipMemcpyAsync(host, c->ctail, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_status != RRI_OK) { rri_status r = c->comm_status; c->comm_status = RRI_OK; return r; }
+    return RRI_OK;
+}
 
 KParams kparams(const rri_ctx* c) {
     KParams p{};
@@ -251,48 +403,60 @@ int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the re
 template <typename SX>
 struct LaunchX {
     typedef SX Elem;
-    // row-dot slots of the 4 waves, the active W column, (UPD: the rank-one row factors,) the row-sum tiles
-    static size_t pass_shmem(const rri_ctx* c, bool upd) { return ((upd ? 6 : 5) * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
-    template <bool DO_Y, bool DO_Z, bool UPD, int U, bool NT, bool RS>
-    static void pass_k(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a, const double* b,
-                       const TgramJob& job) {
-        const int ncols = (int)std::min<i64>(c->ldx, c->LD);
-        typedef typename std::conditional<UPD, SX, const SX>::type XT;
+    // row-dot slots of the 4 waves, the active W column, (UPD: one or two arrays of rank-one row factors,) the row-sum tiles
+    static size_t pass_shmem(const rri_ctx* c, int upd) { return ((5 + upd) * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
+    // the rank-one terms a pass folds into the residual before it takes its products (UPD = 1: a, b; UPD = 2: also a2 and
+    // b2 - b2sub)
+    struct Upd {
+        const double *a = nullptr, *b = nullptr, *a2 = nullptr, *b2 = nullptr, *b2sub = nullptr;
+    };
+    template <bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS>
+    static void pass_k(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u, const TgramJob& job) {
+        const int ncols = (int)std::min<i64>(ldp, c->LD);
+        typedef typename std::conditional<(UPD > 0), SX, const SX>::type XT;
         hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
-                           pass_shmem(c, UPD), c->stream, (XT*)Xp, c->ldx, (int)c->n, ncols, trow, wc, c->Ypart,
-                           c->Zpart, c->LD, c->rpb, c->npanels, a, b, (const DevState*)c->st, job,
+                           pass_shmem(c, UPD), c->stream, (XT*)Xp, ldp, (int)c->n, ncols, trow, wc, c->Ypart,
+                           c->Zpart, c->LD, c->rpb, c->npanels, u.a, u.b, u.a2, u.b2, u.b2sub, (const DevState*)c->st, job,
                            (g_pass_interleave == 1 || (g_pass_interleave < 0 && c->npanels * c->nrb <= 1024)) ? c->nrb : 0);
     }
-    template <bool DO_Y, bool DO_Z, bool UPD>
-    static void pass_cfg(rri_ctx* c, void* Xp, const double* trow, const double* wc, const double* a,
-                         const double* b, const TgramJob& job = TgramJob{}) {
+    template <bool DO_Y, bool DO_Z, int UPD>
+    static void pass_cfg(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u = Upd{},
+                         const TgramJob& job = TgramJob{}) {
         if (g_pass_unroll == 8 && g_pass_rs && DO_Y) {
-            if (g_pass_nt) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, trow, wc, a, b, job);
-            else pass_k<DO_Y, DO_Z, UPD, 8, false, true>(c, Xp, trow, wc, a, b, job);
+            if (g_pass_nt) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, ldp, trow, wc, u, job);
+            else pass_k<DO_Y, DO_Z, UPD, 8, false, true>(c, Xp, ldp, trow, wc, u, job);
             return;
         }
         const int key = g_pass_unroll * 2 + (g_pass_nt ? 1 : 0);
         switch (key) {
-#define RRI_CASE(U_)                                                                                 \
-    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false, false>(c, Xp, trow, wc, a, b, job); break;   \
-    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true, false>(c, Xp, trow, wc, a, b, job); break;
+#define RRI_CASE(U_)                                                                              \
+    case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false, false>(c, Xp, ldp, trow, wc, u, job); break;   \
+    case U_ * 2 + 1: pass_k<DO_Y, DO_Z, UPD, U_, true, false>(c, Xp, ldp, trow, wc, u, job); break;
             RRI_CASE(4)
             RRI_CASE(8)
             RRI_CASE(16)
 #undef RRI_CASE
-            default: pass_k<DO_Y, DO_Z, UPD, 8, true, false>(c, Xp, trow, wc, a, b, job);
+            default: pass_k<DO_Y, DO_Z, UPD, 8, true, false>(c, Xp, ldp, trow, wc, u, job);
         }
     }
     // row dots against T[t,:] (DO_Y) and column sums against W[:,tz] (DO_Z); `job`: the Gram row of T[t,:] rides along
     template <bool DO_Y, bool DO_Z>
     static void pass(rri_ctx* c, int t, int tz, const TgramJob& job = TgramJob{}) {
         TimedScope ts(c, 0);
-        pass_cfg<DO_Y, DO_Z, false>(c, c->X, c->T + (i64)t * c->LD, c->W + (i64)tz * c->ldw, nullptr, nullptr, job);
+        pass_cfg<DO_Y, DO_Z, 0>(c, c->X, c->ldx, c->T + (i64)t * c->LD, c->W + (i64)tz * c->ldw, Upd{}, job);
     }
-    // R <- R - a b^T fused with the row dots (against trow) and column sums (against wc) of the new R
-    static void rank1(rri_ctx* c, void* R, const double* a, const double* b, const double* trow, const double* wc) {
+    // explicit-residual schedule: the same products over the stored residual R (c->E, stride LD)
+    static void rpass_colsums(rri_ctx* c, int tz) {
+        TimedScope ts(c, 0);
+        pass_cfg<false, true, 0>(c, c->E, c->LD, nullptr, c->W + (i64)tz * c->ldw);
+    }
+    // R <- R - a b^T [- a2 (b2 - b2sub)^T] fused with the row dots (against trow) and column sums (against wc) of
+    // the new R: the rank-one residual update north_star names
+    static void rank_update(rri_ctx* c, void* R, i64 ldr, const Upd& u, const double* trow, const double* wc,
+                            const TgramJob& job = TgramJob{}) {
         TimedScope ts(c, 3);
-        pass_cfg<true, true, true>(c, R, trow, wc, a, b);
+        if (u.a2) pass_cfg<true, true, 2>(c, R, ldr, trow, wc, u, job);
+        else pass_cfg<true, true, 1>(c, R, ldr, trow, wc, u, job);
     }
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, bool MBITS, int U, bool RS>
     static void wpass_k(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
@@ -526,6 +690,15 @@ struct LaunchX {
     } while (0)
 
 struct LK {  // float64-only kernels
+    // rows of Gpart a column update leaves: one per 64-row tile (k_wcol) or per 256-row block (k_wcol_resid)
+    static int gpart_rows(const rri_ctx* c) { return c->explicit_resid ? c->nwb256 : c->nwb; }
+    template <bool UPDATE>
+    static void wcol_resid(rri_ctx* c, int t, int tn, int sweep) {
+        TimedScope ts(c, 1);
+        hipLaunchKernelGGL((k_wcol_resid<UPDATE>), dim3(c->nwb256), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n,
+                           c->k, t, tn, (const double*)c->Ypart, c->npanels, (const double*)c->Ttpart, c->nsplit,
+                           c->dwv, c->Gpart, sweep, kparams(c), c->st);
+    }
     static size_t wcol_shmem(const rri_ctx* c) { return (size_t)(2 * c->k + 2 + 256 + 64) * sizeof(double); }
     template <bool UPDATE, bool CARRY>
     static void wcol_src(rri_ctx* c, int t, int tn, int sweep, const double* ypart, int nslices) {
@@ -545,25 +718,26 @@ struct LK {  // float64-only kernels
     static void reduce(rri_ctx* c) {
         const int nb = (int)((c->LD + 31) / 32) + GRAM_SLICES;
         hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
-                           (const double*)c->Gpart, c->nwb, c->k, c->red, (const DevState*)c->st);
+                           (const double*)c->Gpart, gpart_rows(c), c->k, c->red, (const DevState*)c->st);
     }
     // no simplex projection configured: k_trow_numer stores the row itself and k_tgram finishes the checks
     static bool light(const rri_ctx* c) { return !(c->prm.project_T_each_iter && c->prm.has_t_row_sum); }
     static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
         hipLaunchKernelGGL(k_trow_numer, dim3(c->ntb), dim3(128), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, check_prev, tprev, sweep,
-                           kparams(c), c->st);
+                           kparams(c), c->st, c->explicit_resid ? 1 : 0, c->explicit_resid ? c->told : (double*)nullptr);
         c->tpart_n = c->ntb;
         trow_final_if_needed(c, t, sweep, force_final);
     }
     // launch-bound sizes: k_reduce and k_trow_numer as one launch (every workgroup reduces the Gram partials itself)
     static bool small(const rri_ctx* c) {
-        return g_trow_small && (double)c->nwb * (c->k + 2) * c->ntb32 <= 4.0e6;
+        return g_trow_small && (double)gpart_rows(c) * (c->k + 2) * c->ntb32 <= 4.0e6;
     }
     static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
         hipLaunchKernelGGL(k_trow_small, dim3(c->ntb32), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
-                           (const double*)c->Zpart, c->nrb, (const double*)c->Gpart, c->nwb, c->red, c->LD, c->xraw,
-                           c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st);
+                           (const double*)c->Zpart, c->nrb, (const double*)c->Gpart, gpart_rows(c), c->red, c->LD, c->xraw,
+                           c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st, c->explicit_resid ? 1 : 0,
+                           c->explicit_resid ? c->told : (double*)nullptr);
         c->tpart_n = c->ntb32;
         trow_final_if_needed(c, t, sweep, force_final);
     }
@@ -586,7 +760,7 @@ struct LK {  // float64-only kernels
                            c->ldw, (int)c->n, t, (const DevState*)c->st);
     }
     static void check_wcol(rri_ctx* c, int tprev, int sweep, int pos) {
-        hipLaunchKernelGGL(k_check_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb, c->k,
+        hipLaunchKernelGGL(k_check_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, gpart_rows(c), c->k,
                            tprev, sweep, pos, kparams(c), c->st);
     }
     static void proj_rows(rri_ctx* c, double s, const double* svec) {
@@ -716,11 +890,33 @@ void drop_graph(rri_ctx* c) {
 }
 
 // ---- the topic-step scheduler ------------------------------------------------------------------
+// The column verdict of _check_reset_W / the assert of nmf.py:471-476 from the partial sums in Gpart, taken NOW
+// (where no T-row step follows that would carry it).  Row-sharded: the column sum is global, so the local share is
+// all-reduced first (2 doubles) and every rank reaches the same verdict.
+void wcheck_now(rri_ctx* c, int tprev, int sweep, int pos) {
+    if (!c->comm) {
+        if (c->weighted)
+            hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, c->k,
+                               tprev, sweep, pos, kparams(c), c->st, (double*)nullptr);
+        else LK::check_wcol(c, tprev, sweep, pos);
+        return;
+    }
+    if (c->weighted)
+        hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, c->k,
+                           tprev, sweep, pos, kparams(c), c->st, c->ctail);
+    else
+        hipLaunchKernelGGL(k_colsum_tail, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, LK::gpart_rows(c),
+                           c->k, c->ctail, (const DevState*)c->st);
+    comm_allreduce(c, c->ctail, 2);
+    hipLaunchKernelGGL(k_wcheck_tail, dim3(1), dim3(64), 0, c->stream, (const double*)c->ctail, tprev, sweep, pos,
+                       kparams(c), c->st);
+}
+
 // carry := Zpart/Gpart hold the partial sums of topic `carry_topic`.
 void enqueue_prologue(rri_ctx* c, int t, int sweep) {
     // the pending W-column check reads Gpart, which the prologue overwrites: resolve it first
     if (c->pending_wcheck) {
-        LK::check_wcol(c, c->pending_wcheck_topic, sweep, t);
+        wcheck_now(c, c->pending_wcheck_topic, sweep, t);
         c->pending_wcheck = false;
     }
     LK::wcol<false, true>(c, t, t, sweep);                             // Gram row of w_t
@@ -734,10 +930,13 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     {
         TimedScope ts(c, 2);
         const int chk = c->pending_wcheck ? 1 : 0;
-        if (LK::small(c)) {
+        if (LK::small(c) && !c->comm) {
             LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
         } else {
+            // the one cross-row reduction of a topic step: [w_t^T X | slices of (w_t^T W, ||w_t||^2, sum W[:,t-1])];
+            // row-sharded, the ranks all-reduce it here, on the stream, between the two kernels
             LK::reduce(c);
+            comm_allreduce(c, c->red, c->LD + (i64)GRAM_SLICES * (c->k + 2));
             LK::trow(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
         }
         c->pending_wcheck = false;
@@ -787,10 +986,93 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
         // position of the NEXT step, where a resumed run continues
         int ns = sweep, np = t + 1;
         if (np == k) { np = 0; ns = sweep + 1; }
-        LK::check_wcol(c, t, ns, np);
+        wcheck_now(c, t, ns, np);
         c->carry_valid = false;
     }
     c->resid_valid = false;
+}
+
+// ---- explicit-residual schedule (RRI_UNWEIGHTED_RESIDUAL; SURVEY 8a "explicit-residual variant") --------------
+// R = X - W T is kept in HBM (c->E) and every topic step is ONE read-modify-write pass over it:
+//     pass of step t   R <- R - dw_{t-1} t_{t-1}^T - w_t dt_t^T   (the two rank-one terms pending since the W half of
+//                      step t-1 and the T half of step t), fused with  y = R t_t  and  z = R^T w_{t+1}  of the new R
+//     W half           numer_W = y + w_t ||t_t||^2 ;  dw_t = w_t' - w_t stays pending
+//     T half (t+1)     numer_T = z - t_t <dw_t, w_{t+1}> + t_{t+1} ||w_{t+1}||^2   (column t+1 of W is untouched by
+//                      step t, so z needs only the rank-one correction for the term that is still pending)
+// 2 n d s bytes per topic step.  R is rebuilt from X, W, T (the k-panel GEMM k_resid_mfma) once per sweep, so the
+// rounding of the stored residual never accumulates over more than k updates.  carry := Zpart / Gpart hold z and
+// the correction coefficients for topic `carry_topic`.
+void r_refresh(rri_ctx* c) {
+    DISPATCH(c, L::resid(c, false, true, nullptr, nullptr));   // R = X - W T
+    c->resid_valid = true;
+    c->resid_fresh = true;
+    c->dw_pending = false;     // the rebuilt R contains the current W and T
+    c->dt_pending = false;
+}
+
+void enqueue_rT_half(rri_ctx* c, int sweep, int t, bool standalone) {
+    if (!c->resid_valid) r_refresh(c);
+    if (!c->carry_valid || c->carry_topic != t) {
+        if (c->pending_wcheck) {            // reads Gpart, which the prologue overwrites
+            LK::check_wcol(c, c->pending_wcheck_topic, sweep, t);
+            c->pending_wcheck = false;
+        }
+        if (c->dw_pending) r_refresh(c);    // no pass to fold the pending column change into: rebuild instead
+        LK::wcol_resid<false>(c, t, t, sweep);             // ||w_t||^2
+        DISPATCH(c, L::rpass_colsums(c, t));               // R^T w_t
+        c->carry_valid = true;
+        c->carry_topic = t;
+    }
+    {
+        TimedScope ts(c, 2);
+        const int chk = c->pending_wcheck ? 1 : 0;
+        if (LK::small(c)) {
+            LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
+        } else {
+            LK::reduce(c);
+            LK::trow(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
+        }
+        c->pending_wcheck = false;
+    }
+    c->carry_valid = false;
+    c->resid_fresh = false;
+    c->dt_pending = true;     // told holds the previous row: R lacks w_t (T[t,:] - told)^T
+    c->xy_valid = false;
+}
+
+void enqueue_rW_half(rri_ctx* c, int sweep, int t) {
+    const int k = c->k;
+    const int tn = (t + 1) % k;
+    if (!c->resid_valid) r_refresh(c);
+    const int finish = (LK::light(c) && !c->skip_row_finish) ? 1 : 0;
+    c->skip_row_finish = false;
+    TgramJob job{};
+    if (g_side_jobs == 0) {
+        TimedScope ts(c, 2);
+        LK::tgram(c, t, finish, sweep);
+    } else {
+        job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n,
+                       c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
+    }
+    const double* trow = c->T + (i64)t * c->LD;
+    DISPATCH(c, {
+        typename L::Upd u;
+        u.a = c->dw_pending ? c->dwv : c->zeros;
+        u.b = c->T + (i64)(c->dw_pending ? c->dw_topic : t) * c->LD;
+        u.a2 = c->W + (i64)t * c->ldw;               // the column BEFORE its update below
+        u.b2 = trow;
+        u.b2sub = c->dt_pending ? c->told : trow;    // no T half since the last pass: dt = 0
+        L::rank_update(c, c->E, c->LD, u, trow, c->W + (i64)tn * c->ldw, job);
+    });
+    LK::wcol_resid<true>(c, t, tn, sweep);
+    c->dw_pending = true;
+    c->dw_topic = t;
+    c->dt_pending = false;
+    c->resid_fresh = false;
+    c->carry_valid = true;
+    c->carry_topic = tn;
+    c->pending_wcheck = true;
+    c->pending_wcheck_topic = t;
 }
 
 // ---- weighted flavour (rri_wrri_kernels.hpp) ---------------------------------------------------------
@@ -845,6 +1127,21 @@ void enqueue_wT_solve(rri_ctx* c, int sweep, int t) {
 
 void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
     enqueue_wT_sums(c, t);
+    if (c->comm) {
+        // row-sharded: red = [numerator | denominator | sum of the last updated column, its negative-denominator flag]
+        // is all-reduced; the pending column verdict is taken from the reduced tail (option A)
+        double* tail = c->red + 2 * c->LD;
+        if (c->pending_wcheck)
+            hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, c->k,
+                               c->pending_wcheck_topic, sweep, t, kparams(c), c->st, tail);
+        else
+            (void)hipMemsetAsync(tail, 0, 2 * sizeof(double), c->stream);
+        comm_allreduce(c, c->red, 2 * c->LD + 2);
+        if (c->pending_wcheck)
+            hipLaunchKernelGGL(k_wcheck_tail, dim3(1), dim3(64), 0, c->stream, (const double*)tail, c->pending_wcheck_topic,
+                               sweep, t, kparams(c), c->st);
+        c->pending_wcheck = false;
+    }
     enqueue_wT_solve(c, sweep, t);
 }
 
@@ -869,12 +1166,11 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     else DISPATCH(c, (L::template wpass<false, false, true, true>(c, nullptr, nullptr, c->wold, b1, c->dwv, trow)));
     int ns = sweep, np = t + 1;
     if (np == k) { np = 0; ns = sweep + 1; }
-    if (defer_check) {   // row-sharded: the verdict needs the global column sum (rri_topic_reduce_local parks it)
+    if (defer_check) {   // row-sharded: the verdict needs the global column sum; it rides on the next topic's all-reduce
         c->pending_wcheck = true;
         c->pending_wcheck_topic = t;
     } else {
-        hipLaunchKernelGGL(k_wcheck_wcol, dim3(1), dim3(256), 0, c->stream, (const double*)c->Gpart, c->nwb256, k, t, ns,
-                           np, kparams(c), c->st, (double*)nullptr);
+        wcheck_now(c, t, ns, np);
     }
     c->carry_valid = carry_next;
     c->carry_topic = tn;
@@ -893,7 +1189,22 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) 
                 // once per sweep (and after resets), unless rri_objective has just rebuilt it from the same W, T
                 if (!c->resid_valid || (t == 0 && ph == 0 && !c->resid_fresh)) w_refresh(c);
                 if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, sa, t);
-                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t);
+                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t, c->comm != nullptr && !c->prm.fix_T);
+            }
+        }
+        return;
+    }
+    if (c->explicit_resid) {
+        for (int s = cur.sweep; s < s_end; ++s) {
+            const int t0 = (s == cur.sweep) ? cur.topic : 0;
+            const int sa = s - sweep_arg_offset;
+            for (int t = t0; t < k; ++t) {
+                const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
+                // rebuilt once per sweep (and after anything changed W or T from outside), unless rri_objective has
+                // just stored it for the same W, T
+                if (!c->resid_valid || (t == 0 && ph == 0 && !c->resid_fresh)) r_refresh(c);
+                if (ph == 0) enqueue_rT_half(c, sa, t, false);
+                enqueue_rW_half(c, sa, t);
             }
         }
         return;
@@ -911,7 +1222,7 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) 
 
 void enqueue_final_check(rri_ctx* c, int sweep_arg) {
     if (c->pending_wcheck) {  // last column of the call: report it in this call
-        LK::check_wcol(c, c->pending_wcheck_topic, sweep_arg, 0);
+        wcheck_now(c, c->pending_wcheck_topic, sweep_arg, 0);
         c->pending_wcheck = false;
     }
 }
@@ -943,6 +1254,13 @@ void restore_steady(rri_ctx* c, const SteadyState& s) {
 rri_status read_state(rri_ctx* c, DevState* out) {
     HIPCHK(c, hipMemcpyAsync(out, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_status != RRI_OK) {   // a collective of the sequence just run failed: its text is in c->err
+        const rri_status r = c->comm_status;
+        c->comm_status = RRI_OK;
+        invalidate(c);
+        c->pending_wcheck = false;
+        return r;
+    }
     return RRI_OK;
 }
 
@@ -1012,8 +1330,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, RRI_ERR_HIP, "no HIP device available (librri_hip needs an MI355X)");
     if (device < 0 || device >= ndev) return fail(nullptr, RRI_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
-    if (weighted < 0 || weighted > 2) return fail(nullptr, RRI_ERR_INVALID, "weighted must be 0, 1 or 2 (sparse pattern)");
+    if (weighted < 0 || weighted > 3)
+        return fail(nullptr, RRI_ERR_INVALID, "weighted must be RRI_UNWEIGHTED, RRI_WEIGHTED_DENSE, RRI_WEIGHTED_SPARSE or RRI_UNWEIGHTED_RESIDUAL");
     rri_ctx* c = new rri_ctx();
+    const bool explicit_resid = weighted == RRI_UNWEIGHTED_RESIDUAL;
+    if (explicit_resid) weighted = RRI_UNWEIGHTED;   // the same flavour of the algorithm, another schedule of its passes
+    c->explicit_resid = explicit_resid;
     c->n = n; c->d = d; c->k = k; c->dtype = dtype; c->weighted = weighted; c->device = device;
     c->sparse = weighted == RRI_WEIGHTED_SPARSE;
     c->kp = (int)round_up(k, 8);
@@ -1051,7 +1373,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     // LDS per workgroup = (5 rows-doubles plain | 11 weighted) * rpb + 4 row-sum tiles (18 KiB): kept under 40 KiB so
     // that 4 workgroups (16 waves) fit a CU's 160 KiB -- with 62 KiB the weighted passes ran at 2 workgroups per CU
     // and 20 % slower.  (The explicit update kernel takes a sixth array and may run at 3 per CU.)
-    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : 5) * 8)) / 16 * 16;
+    const i64 rpb_cap = ((40 * 1024 - 4 * 8 * 72 * 8) / ((weighted ? 11 : explicit_resid ? 7 : 5) * 8)) / 16 * 16;
     int rpb_min = 32;
     if (const char* e = getenv("RRI_PASS_MIN_ROWS")) rpb_min = std::max(4, atoi(e));
     i64 rpb = 0;
@@ -1146,6 +1468,17 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
             CR(hipMemsetAsync(c->sp_Tt, 0, (size_t)d * c->kp * f8, c->stream));
         }
     }
+    if (explicit_resid) {
+        const i64 zn = std::max<i64>(c->LD, n);
+        CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+        if (c->LD != d) CR(hipMemsetAsync(c->E, 0, (size_t)n * c->LD * es_x, c->stream));   // pad columns stay zero
+        CR(hipMalloc((void**)&c->dwv, (size_t)n * f8));
+        CR(hipMemsetAsync(c->dwv, 0, (size_t)n * f8, c->stream));
+        CR(hipMalloc((void**)&c->told, (size_t)c->LD * f8));
+        CR(hipMemsetAsync(c->told, 0, (size_t)c->LD * f8, c->stream));
+        CR(hipMalloc((void**)&c->zeros, (size_t)zn * f8));
+        CR(hipMemsetAsync(c->zeros, 0, (size_t)zn * f8, c->stream));
+    }
     CR(hipMalloc((void**)&c->st, sizeof(DevState)));
     CR(hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream));
     // opt in to large dynamic LDS where a kernel needs it
@@ -1168,7 +1501,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -1508,6 +1841,8 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
     if (p->has_w_row_sum && !(p->w_row_sum > 0)) return fail(c, RRI_ERR_INVALID, "w_row_sum must be > 0");
     if (p->reset_method < 0 || p->reset_method > 2) return fail(c, RRI_ERR_INVALID, "bad reset_method");
     if (p->fix_W && p->fix_T) return fail(c, RRI_ERR_INVALID, "fix_W and fix_T together leave nothing to update");
+    if (c->explicit_resid && (p->fix_W || p->fix_T || c->k < 2))
+        return fail(c, RRI_ERR_UNSUPPORTED, "the explicit-residual schedule needs k >= 2 and both halves free");
     c->prm = *p;
     c->have_params = true;
     drop_graph(c);
@@ -1528,7 +1863,7 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
 
 // launch-bound sizes only: where one streaming pass takes well under ~100 us the gaps between launches show
 static bool graph_wanted(const rri_ctx* c) {
-    if (g_graph == 0 || c->timing > 0) return false;
+    if (g_graph == 0 || c->timing > 0 || c->explicit_resid || c->comm) return false;
     if (g_graph == 2) return true;
     const double bytes = c->sparse ? 16.0 * (double)c->nnz : (double)c->n * (double)c->LD * (double)c->es;
     return bytes <= 512e6;
@@ -1629,6 +1964,34 @@ rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen)
     DISPATCH(c, L::resid(c, false, false, nullptr, c->rowpos));
     hipLaunchKernelGGL(k_vec_sum_argmax, dim3(1), dim3(1024), 0, c->stream, (const double*)c->rowpos, c->n,
                        (double*)nullptr, c->itmp);
+    if (c->comm) {
+        // row-sharded (nmf.py:771-776 over all rows): every rank offers its largest row-residual norm, the global
+        // winner -- lowest global row index on ties, as np.argmax -- broadcasts max(X[mi,:] - W[mi,:] T, 0); T[t,:]
+        // becomes that row on every rank, W[:,t] the unit vector of the winning row
+        rri_comm* m = c->comm;
+        hipLaunchKernelGGL(k_pack_candidate, dim3(1), dim3(1), 0, c->stream, (const double*)c->rowpos,
+                           (const i64*)c->itmp, c->row_offset, c->ctail);
+        comm_allgather(c, c->ctail, 2, c->cand);
+        std::vector<double> cand((size_t)2 * m->world);
+        HIPCHK(c, hipMemcpyAsync(cand.data(), c->cand, cand.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int win = 0;
+        for (int r = 1; r < m->world; ++r)
+            if (cand[2 * r] > cand[2 * win] || (cand[2 * r] == cand[2 * win] && cand[2 * r + 1] < cand[2 * win + 1])) win = r;
+        if (m->rank == win) DISPATCH(c, L::reset_row(c));          // xraw = the reset row (d doubles)
+        comm_broadcast(c, c->xraw, c->LD, win);
+        if (m->rank != win) {
+            const i64 none = -1;
+            HIPCHK(c, hipMemcpyAsync(c->itmp, &none, sizeof(i64), hipMemcpyHostToDevice, c->stream));
+        }
+        LK::reset_commit(c, t);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->comm_status != RRI_OK) { const rri_status r = c->comm_status; c->comm_status = RRI_OK; return r; }
+        if (row_chosen) *row_chosen = (int64_t)cand[2 * win + 1];
+        if (c->paused && c->pending.kind != RRI_EVENT_NONE) event_resolved(c);
+        else invalidate(c);
+        return RRI_OK;
+    }
     DISPATCH(c, L::reset_row(c));
     LK::reset_commit(c, t);
     i64 mi = -1;
@@ -1677,7 +2040,8 @@ rri_status rri_update_T_row(rri_ctx* c, int32_t t) {
     c->run_total = 1;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
-    enqueue_T_half(c, 0, t, true);
+    if (c->explicit_resid) enqueue_rT_half(c, 0, t, true);
+    else enqueue_T_half(c, 0, t, true);
     DevState s;
     r = read_state(c, &s);
     if (r != RRI_OK) return r;
@@ -1695,9 +2059,10 @@ rri_status rri_update_W_col(rri_ctx* c, int32_t t) {
     r = clear_halt(c);
     if (r != RRI_OK) return r;
     c->skip_row_finish = true;   // a lone W half: the T-row checks belong to rri_update_T_row
-    enqueue_W_half(c, 0, t);
+    if (c->explicit_resid) enqueue_rW_half(c, 0, t);
+    else enqueue_W_half(c, 0, t);
     if (c->pending_wcheck) {
-        LK::check_wcol(c, c->pending_wcheck_topic, 1, 0);
+        wcheck_now(c, c->pending_wcheck_topic, 1, 0);
         c->pending_wcheck = false;
     }
     DevState s;
@@ -1803,6 +2168,14 @@ static rri_status objective_terms(rri_ctx* c, double out[3], double* tn) {
         out[2] = w1;
         if (tn) { tn[0] = 0.0; tn[1] = t2; tn[2] = t1; }
         return RRI_OK;
+    } else if (c->explicit_resid) {
+        // the objective is 1/2 ||R||^2 of the residual this schedule keeps: store it while it is computed, and the
+        // sweep that follows skips its own rebuild
+        DISPATCH(c, L::resid(c, false, true, c->rowobj, nullptr));
+        c->resid_valid = true;
+        c->resid_fresh = true;
+        c->dw_pending = false;
+        c->dt_pending = false;
     } else {
         DISPATCH(c, L::resid(c, false, false, c->rowobj, nullptr));
     }
@@ -1828,6 +2201,8 @@ rri_status rri_objective(rri_ctx* c, double* out) {
     if (!out) return fail(c, RRI_ERR_INVALID, "out is NULL");
     double parts[3], nt[3];
     rri_status r = objective_terms(c, parts, nt);
+    if (r != RRI_OK) return r;
+    r = comm_allreduce_host(c, parts, 3);    // row-sharded: the terms over rows are sums over the ranks; T is replicated
     if (r != RRI_OK) return r;
     const rri_params& q = c->prm;
     // base + wr2 + tr2 + tr1 + wr1 (nmf.py:83-91)
@@ -1898,6 +2273,74 @@ rri_status rri_rollback(rri_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate(c);
     c->q_valid = false;
+    c->pending_wcheck = false;
+    return RRI_OK;
+}
+
+// ---- the explicit residual (RRI_UNWEIGHTED_RESIDUAL handles) --------------------------------------------------
+rri_status rri_residual_rebuild(rri_ctx* c) {
+    CHECK_CTX(c);
+    if (!c->explicit_resid) return fail(c, RRI_ERR_INVALID, "handle was not created with RRI_UNWEIGHTED_RESIDUAL");
+    if (!c->have_X || !c->have_W || !c->have_T) return fail(c, RRI_ERR_INVALID, "X, W, T must be set");
+    HIPCHK(c, hipSetDevice(c->device));
+    r_refresh(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RRI_OK;
+}
+
+rri_status rri_get_residual(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
+    CHECK_CTX(c);
+    if (!c->explicit_resid) return fail(c, RRI_ERR_INVALID, "handle was not created with RRI_UNWEIGHTED_RESIDUAL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return to_host(c, c->E, c->LD, host, ld, host_dtype, c->n, c->d, c->dtype);
+}
+
+rri_status rri_residual_update(rri_ctx* c, const double* a, const double* b, const double* a2, const double* b2,
+                               const double* trow, const double* wcol, double* y_out, double* z_out) {
+    CHECK_CTX(c);
+    if (!c->explicit_resid) return fail(c, RRI_ERR_INVALID, "handle was not created with RRI_UNWEIGHTED_RESIDUAL");
+    if (!a || !b || !trow || !wcol || ((a2 == nullptr) != (b2 == nullptr)))
+        return fail(c, RRI_ERR_INVALID, "a, b, trow, wcol are required; a2 and b2 come together");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    // row vectors (n) and column vectors (padded to LD with zeros) on the device
+    DevTmp rows, cols;
+    HIPCHK(c, rows.alloc((size_t)3 * c->n * sizeof(double)));
+    HIPCHK(c, cols.alloc((size_t)3 * c->LD * sizeof(double)));
+    double* dr = (double*)rows.p;
+    double* dc = (double*)cols.p;
+    HIPCHK(c, hipMemsetAsync(dc, 0, (size_t)3 * c->LD * sizeof(double), c->stream));
+    const double* hr[3] = {a, a2, wcol};
+    const double* hc[3] = {b, b2, trow};
+    for (int q = 0; q < 3; ++q) {
+        if (hr[q]) HIPCHK(c, hipMemcpyAsync(dr + (i64)q * c->n, hr[q], (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (hc[q]) HIPCHK(c, hipMemcpyAsync(dc + (i64)q * c->LD, hc[q], (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    DISPATCH(c, {
+        typename L::Upd u;
+        u.a = dr;
+        u.b = dc;
+        if (a2) { u.a2 = dr + c->n; u.b2 = dc + c->LD; u.b2sub = c->zeros; }
+        L::rank_update(c, c->E, c->LD, u, dc + 2 * c->LD, dr + 2 * c->n);
+    });
+    // z: the row-block partials in a fixed order (k_reduce); y: the column-panel partials, added here in panel order
+    const int nb = (int)((c->LD + 31) / 32);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
+                       (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
+    if (z_out) HIPCHK(c, hipMemcpyAsync(z_out, c->red, (size_t)c->d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> yp;
+    if (y_out) {
+        yp.resize((size_t)c->npanels * c->n);
+        HIPCHK(c, hipMemcpyAsync(yp.data(), c->Ypart, yp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (y_out)
+        for (i64 i = 0; i < c->n; ++i) {
+            double sacc = 0.0;
+            for (int pgi = 0; pgi < c->npanels; ++pgi) sacc += yp[(size_t)pgi * c->n + i];
+            y_out[i] = sacc;
+        }
+    invalidate(c);            // Zpart / red were used, and R no longer equals X - W T for the handle's factors
     c->pending_wcheck = false;
     return RRI_OK;
 }
@@ -2011,7 +2454,7 @@ rri_status rri_scale_X(rri_ctx* c, const double* col_scale, int32_t normalize_ro
         // row sums of X * col_scale = the row dots of the streaming pass against col_scale
         const int tsave = c->timing;
         c->timing = 0;
-        DISPATCH(c, (L::template pass_cfg<true, false, false>(c, c->X, sdev, c->W, nullptr, nullptr)));
+        DISPATCH(c, (L::template pass_cfg<true, false, 0>(c, c->X, c->ldx, sdev, c->W)));
         c->timing = tsave;
         hipLaunchKernelGGL(k_row_inverse, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
                            (const double*)c->Ypart, c->npanels, (int)c->n, invdev);
@@ -2052,6 +2495,8 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
     if (r != RRI_OK) return r;
     if (c->prm.fix_W || c->prm.fix_T || c->k < 2)
         return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping needs k >= 2 and both halves free");
+    if (c->explicit_resid) return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping runs the Gram-form schedule only");
+    if (c->comm) return fail(c, RRI_ERR_INVALID, "a communicator is attached: rri_sweep does the collectives itself");
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->weighted) {
@@ -2183,6 +2628,118 @@ rri_status rri_poll(rri_ctx* c) {
     return r;
 }
 
+// ---- the communicator (one per process and group of ranks) ------------------------------------------------------
+rri_status rri_comm_unique_id(uint8_t* id_out) {
+    if (!id_out) return RRI_ERR_INVALID;
+    RcclApi& a = rccl_api();
+    if (!a.ok) return fail(nullptr, RRI_ERR_COMM, "%s", a.err.c_str());
+    static_assert(sizeof(ncclUniqueId) == RRI_COMM_ID_BYTES, "RRI_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    ncclUniqueId id;
+    ncclResult_t r = a.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, RRI_ERR_COMM, "ncclGetUniqueId: %s", a.GetErrorString(r));
+    memcpy(id_out, &id, sizeof id);
+    return RRI_OK;
+}
+
+rri_status rri_comm_create(rri_comm** out, const uint8_t* id, int32_t rank, int32_t world, int32_t device) {
+    if (!out) return RRI_ERR_INVALID;
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(nullptr, RRI_ERR_INVALID, "bad rank / world / id");
+    RcclApi& a = rccl_api();
+    if (!a.ok) return fail(nullptr, RRI_ERR_COMM, "%s", a.err.c_str());
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, RRI_ERR_HIP, "hipSetDevice(%d) failed", device);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = a.CommInitRank(&comm, world, uid, rank);
+    if (r != ncclSuccess) return fail(nullptr, RRI_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, world, a.GetErrorString(r));
+    rri_comm* m = new rri_comm();
+    m->rank = rank; m->world = world; m->device = device; m->nccl = comm;
+    *out = m;
+    return RRI_OK;
+}
+
+rri_status rri_comm_create_host(rri_comm** out, int32_t rank, int32_t world, rri_allreduce_fn allreduce,
+                                rri_allgather_fn allgather, rri_broadcast_fn broadcast, void* user) {
+    if (!out) return RRI_ERR_INVALID;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !allreduce || !allgather || !broadcast)
+        return fail(nullptr, RRI_ERR_INVALID, "bad rank / world / callbacks");
+    rri_comm* m = new rri_comm();
+    m->rank = rank; m->world = world;
+    m->h_allreduce = allreduce; m->h_allgather = allgather; m->h_broadcast = broadcast; m->user = user;
+    *out = m;
+    return RRI_OK;
+}
+
+rri_status rri_comm_destroy(rri_comm* m) {
+    if (!m) return RRI_OK;
+    if (m->nccl) {
+        (void)hipSetDevice(m->device);
+        (void)rccl_api().CommDestroy(m->nccl);
+    }
+    delete m;
+    return RRI_OK;
+}
+
+rri_status rri_attach_comm(rri_ctx* c, rri_comm* comm, int64_t row_offset, int64_t n_global) {
+    CHECK_CTX(c);
+    drop_graph(c);
+    if (!comm) {              // detach
+        c->comm = nullptr;
+        c->row_offset = 0;
+        c->n_global = 0;
+        invalidate(c);
+        return RRI_OK;
+    }
+    if (c->explicit_resid) return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded runs use the Gram-form schedule");
+    if (row_offset < 0 || n_global < row_offset + c->n) return fail(c, RRI_ERR_INVALID, "row block [%lld, %lld) outside 0..%lld", (long long)row_offset, (long long)(row_offset + c->n), (long long)n_global);
+    if (comm->nccl && comm->device != c->device) return fail(c, RRI_ERR_INVALID, "communicator lives on device %d, handle on %d", comm->device, c->device);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->ctail) {
+        HIPCHK(c, hipMalloc((void**)&c->ctail, 8 * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->ctail, 0, 8 * sizeof(double), c->stream));
+    }
+    if (c->cand) { (void)hipFree(c->cand); c->cand = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->cand, (size_t)2 * comm->world * sizeof(double)));
+    c->comm = comm;
+    c->row_offset = row_offset;
+    c->n_global = n_global;
+    c->comm_status = RRI_OK;
+    invalidate(c);
+    return RRI_OK;
+}
+
+rri_status rri_comm_broadcast(rri_ctx* c, double* host, int64_t count, int32_t root) {
+    CHECK_CTX(c);
+    if (!c->comm) return RRI_OK;                       // one rank: nothing to do
+    if (!host || count < 1 || root < 0 || root >= c->comm->world) return fail(c, RRI_ERR_INVALID, "bad broadcast arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevTmp buf;
+    HIPCHK(c, buf.alloc((size_t)count * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(buf.p, host, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    comm_broadcast(c, (double*)buf.p, count, root);
+    HIPCHK(c, hipMemcpyAsync(host, buf.p, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_status != RRI_OK) { const rri_status r = c->comm_status; c->comm_status = RRI_OK; return r; }
+    return RRI_OK;
+}
+
+rri_status rri_comm_allreduce_sum(rri_ctx* c, double* host, int64_t count) {
+    CHECK_CTX(c);
+    if (!host || count < 1) return fail(c, RRI_ERR_INVALID, "bad all-reduce arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    return comm_allreduce_host(c, host, count);
+}
+
+rri_status rri_comm_stats(rri_ctx* c, int32_t* rank, int32_t* world, int64_t* allreduce_calls) {
+    CHECK_CTX(c);
+    if (rank) *rank = c->comm ? c->comm->rank : 0;
+    if (world) *world = c->comm ? c->comm->world : 1;
+    if (allreduce_calls) *allreduce_calls = c->comm ? c->comm->n_allreduce : 0;
+    return RRI_OK;
+}
+
 // ---- measurement ---------------------------------------------------------------------------------------------
 rri_status rri_timing_enable(rri_ctx* c, int32_t on) {
     CHECK_CTX(c);
@@ -2246,26 +2803,33 @@ rri_status rri_bench_stream_copy(rri_ctx* c, int32_t reps, double* avg_ms) {
 
 rri_status rri_bench_rank1_update(rri_ctx* c, int32_t reps, double* avg_ms) {
     CHECK_CTX(c);
-    if (!c->have_X || reps < 1) return fail(c, RRI_ERR_INVALID, "X must be set and reps >= 1");
+    if (!c->have_X || !c->have_W || !c->have_T || reps < 1 || c->weighted)
+        return fail(c, RRI_ERR_INVALID, "an unweighted handle with X, W, T set and reps >= 1");
     HIPCHK(c, hipSetDevice(c->device));
-    // scratch residual R = copy of X; a = wcol-shaped vector, b = a T row (values are irrelevant to timing,
-    // tiny magnitudes keep R finite over the repetitions)
+    // scratch residual R = copy of X; every repetition folds the rank-one term w_0 t_0^T of the handle's own factors
+    // into it (non-trivial row and column factors; R stays finite: it moves by reps * w_0 t_0^T) and takes the row
+    // dots against T[0,:] and the column sums against W[:,0] of the result -- the work of rri_residual_update
     const size_t bytes = (size_t)c->n * c->ldx * c->es;
     void* R = nullptr;
-    double* a = nullptr;
     HIPCHK(c, hipMalloc(&R, bytes));
-    if (hipMalloc((void**)&a, (size_t)c->n * 8) != hipSuccess) { (void)hipFree(R); return fail(c, RRI_ERR_HIP, "hipMalloc failed"); }
     (void)hipMemcpyAsync(R, c->X, bytes, hipMemcpyDeviceToDevice, c->stream);
-    (void)hipMemsetAsync(a, 0, (size_t)c->n * 8, c->stream);
     (void)hipMemsetAsync(c->st, 0, 16, c->stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     const int tm = c->timing;
     c->timing = 0;
-    DISPATCH(c, L::rank1(c, R, a, c->T, c->T, a));
+    auto once = [&]() {
+        DISPATCH(c, {
+            typename L::Upd u;
+            u.a = c->W;
+            u.b = c->T;
+            L::rank_update(c, R, c->ldx, u, c->T, c->W);
+        });
+    };
+    once();
     (void)hipEventRecord(e0, c->stream);
-    for (int r = 0; r < reps; ++r) DISPATCH(c, L::rank1(c, R, a, c->T, c->T, a));
+    for (int r = 0; r < reps; ++r) once();
     (void)hipEventRecord(e1, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     c->timing = tm;
@@ -2274,7 +2838,6 @@ rri_status rri_bench_rank1_update(rri_ctx* c, int32_t reps, double* avg_ms) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(R);
-    (void)hipFree(a);
     invalidate(c);
     if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "rank-one bench failed: %s", hipGetErrorString(e));
     if (avg_ms) *avg_ms = ms / reps;

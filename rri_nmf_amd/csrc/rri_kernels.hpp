@@ -143,14 +143,18 @@ __device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ld
 // Every wave walks all rows of the block, U rows in flight; the 4 row-dot partials of a row meet in
 // LDS slots [wave][row] and are added in a fixed order at the end (Ypart has one slice per 4 panels);
 // column sums belong to one wave each and go straight to Zpart.
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD, int U, bool NT, bool RS>
-__global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX, const SX>::type* __restrict__ X,
+// UPD = 0: X is read only.  UPD = 1: R <- R - a b^T.  UPD = 2: R <- R - a b^T - a2 (b2 - b2sub)^T, the two pending
+// rank-one terms of one topic step of the explicit-residual schedule (dw_{t-1} t_{t-1}^T and w_t dt_t^T; b2sub = the
+// T row before its update, so dt is formed in registers).  a, a2 come through LDS, b, b2 live in registers.
+template <typename SX, bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS>
+__global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0), SX, const SX>::type* __restrict__ X,
                                               i64 ldx, int n, int ncols,
                                               const double* __restrict__ trow, const double* __restrict__ wcol,
                                               double* __restrict__ Ypart, double* __restrict__ Zpart, i64 ldz,
                                               int rpb, int npg, const double* __restrict__ avec,
-                                              const double* __restrict__ bvec, const DevState* __restrict__ st,
-                                              const TgramJob job, int nrb_il) {
+                                              const double* __restrict__ bvec, const double* __restrict__ avec2,
+                                              const double* __restrict__ bvec2, const double* __restrict__ bsub2,
+                                              const DevState* __restrict__ st, const TgramJob job, int nrb_il) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
@@ -167,10 +171,11 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
     double* ysh = reinterpret_cast<double*>(smem);            // [4 waves][rpb]
     double* wsh = ysh + 4 * rpb;                              // [rpb]
     double* ash = wsh + rpb;                                  // [rpb], only with UPD
+    double* ash2 = ash + rpb;                                 // [rpb], only with UPD == 2
     static_assert(!RS || U == 8, "the LDS row-sum path reduces 8 rows at a time");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* tile = wsh + (UPD ? 2 : 1) * rpb + wave * (8 * 72);   // [4][8*72] private row-sum tiles (RS)
+    double* tile = wsh + (1 + UPD) * rpb + wave * (8 * 72);   // [4][8*72] private row-sum tiles (RS)
     const int pg = bid % npg;
     const int rb = bid / npg;
     // Rows of this block, local index li = q U + u  ->  global row.  Interleaved (nrb_il > 0): chunk q of U rows is
@@ -181,22 +186,24 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
         return nrb_il > 0 ? ((li / U) * nrb_il + rb) * U + (li % U) : rb * rpb + li;
     };
     const int col = (pg * 4 + wave) * PW + lane * VN;
-    if (DO_Z || UPD) {
+    if (DO_Z || UPD > 0) {
         for (int i = threadIdx.x; i < rpb; i += 256) {
             const int g = grow(i);
             if (DO_Z) wsh[i] = g < n ? wcol[g] : 0.0;
-            if (UPD) ash[i] = g < n ? avec[g] : 0.0;
+            if (UPD > 0) ash[i] = g < n ? avec[g] : 0.0;
+            if (UPD > 1) ash2[i] = g < n ? avec2[g] : 0.0;
         }
         __syncthreads();
     }
     const bool ok = col < ncols;
     const bool wave_has_cols = (pg * 4 + wave) * PW < ncols;   // wave-uniform
-    double tv[VN], zacc[VN], bv[VN];
+    double tv[VN], zacc[VN], bv[VN], bv2[VN];
 #pragma unroll
     for (int e = 0; e < VN; ++e) {
         zacc[e] = 0.0;
         tv[e] = (DO_Y && ok) ? trow[col + e] : 0.0;
-        bv[e] = (UPD && ok) ? bvec[col + e] : 0.0;
+        bv[e] = (UPD > 0 && ok) ? bvec[col + e] : 0.0;
+        bv2[e] = (UPD > 1 && ok) ? bvec2[col + e] - bsub2[col + e] : 0.0;
     }
     if (wave_has_cols) {
         for (int l0 = 0; l0 < rpb; l0 += U) {
@@ -213,14 +220,18 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<UPD, SX,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rr = r + u;
-                double wv = 0.0, na = 0.0;
+                double wv = 0.0, na = 0.0, na2 = 0.0;
                 if (DO_Z && rr < n) wv = wsh[l0 + u];
-                if (UPD && rr < n) na = -ash[l0 + u];
+                if (UPD > 0 && rr < n) na = -ash[l0 + u];
+                if (UPD > 1 && rr < n) na2 = -ash2[l0 + u];
                 double xe[VN];
                 XV::unpack(x[u], xe);
-                if constexpr (UPD) {
+                if constexpr (UPD > 0) {
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) xe[e] = fma(na, bv[e], xe[e]);
+                    for (int e = 0; e < VN; ++e) {
+                        xe[e] = fma(na, bv[e], xe[e]);
+                        if (UPD > 1) xe[e] = fma(na2, bv2[e], xe[e]);
+                    }
                     const V rounded = XV::pack(xe);
                     if (rr < n && ok) stream_store<NT>(reinterpret_cast<V*>(X + (i64)rr * ldx + col), rounded);
                     // the stored residual is what later passes read: continue with the ROUNDED values
@@ -511,6 +522,60 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
 }
 
 // =========================================================================================
+// k_wcol_resid: W-column update of topic t in the explicit-residual schedule ("explicit-residual variant"):
+//     numer_W = R t' + w_t ||t'||^2 - reg_w_l1      (R: the stored residual, which already contains w_t t'^T)
+// y = R t' arrives as the row-dot panels of the pass; the new column goes to Wt[t,:], dw = new - old stays in `dw`
+// as the row factor of the rank-one term  - dw t'^T  that the NEXT pass folds into R.  One thread per row.
+// Gpart[b] (k+2 entries per block of 256 rows): [t] = <dw, w_tn> -- the coefficient with which that pending term enters
+// the column sums of the next topic tn --, [k] = ||w_tn||^2, [k+1] = sum of the new column, every other entry 0.
+// UPDATE = false (prologue): only [k] = ||w_tn||^2.
+// =========================================================================================
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_wcol_resid(double* __restrict__ Wt, i64 ldw, int n, int k, int t, int tn,
+                                                    const double* __restrict__ Ypart, int npanels,
+                                                    const double* __restrict__ Ttpart, int nsplit,
+                                                    double* __restrict__ dw, double* __restrict__ Gpart, int sweep,
+                                                    KParams p, DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    double cden = 1.0, nt = 0.0;
+    int mode = 0;
+    if (UPDATE) {
+        nt = ordered_sum<8>(Ttpart + t, k, 0, nsplit, 1);      // ||T[t,:]||^2 from the slices of k_tgram
+        cden = nt + p.reg_w_l2;                                // denom = nt + reg_w_l2 (nmf.py:465)
+        if (!(cden > 0.0)) {
+            if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;     // optimization.py:60-67
+            else {
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                }
+                return;
+            }
+        }
+    }
+    double wnew = 0.0, dwi = 0.0, wn = 0.0;
+    if (i < n) {
+        if (UPDATE) {
+            const double y = ordered_sum<8>(Ypart + i, n, 0, npanels, 1);
+            const double w0 = Wt[(i64)t * ldw + i];
+            const double numer = fma(w0, nt, y) - p.reg_w_l1;
+            if (mode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
+            else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
+            Wt[(i64)t * ldw + i] = wnew;
+            dwi = wnew - w0;
+            dw[i] = dwi;
+        }
+        wn = (UPDATE && tn == t) ? wnew : Wt[(i64)tn * ldw + i];
+    }
+    const double g = block_sum(wn * dwi, scratch);
+    const double nwp = block_sum(wn * wn, scratch);
+    const double sw = block_sum(wnew, scratch);
+    double* gp = Gpart + (i64)blockIdx.x * (k + 2);
+    for (int l = threadIdx.x; l < k + 2; l += 256) gp[l] = (l == t && UPDATE) ? g : (l == k ? nwp : (l == k + 1 ? sw : 0.0));
+}
+
+// =========================================================================================
 // k_reduce: fixed-order reduction of the row-block partials into the reduce buffer
 //   red[0..ldz) = w^T X ; red[ldz + g*(k+2) + ...), g < GRAM_SLICES: slice sums of [w^T W | ||w||^2 | sum W[:,tprev]]
 // (in the row-sharded multi-GPU run this buffer is what the ranks all-reduce).
@@ -577,7 +642,11 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
                                                     const double* __restrict__ red, i64 ldz,
                                                     double* __restrict__ xraw, double* __restrict__ tpart,
                                                     i64* __restrict__ tpart_idx, int check_prev, int tprev,
-                                                    int sweep, KParams p, DevState* st) {
+                                                    int sweep, KParams p, DevState* st, int resid_form,
+                                                    double* __restrict__ told) {
+    // resid_form (explicit-residual schedule): red[0..d) = R^T w_t over the stored residual, the Gram part holds the
+    // coefficient of the one pending rank-one term (slot tprev: <dw_tprev, w_t>) and zeros; the topic's own term
+    // comes back as + ||w_t||^2 T[t,:]  (numer_T = R^T w + t ||w||^2).  told: the row before its update.
     if (st->halt) return;
     const int tid = threadIdx.x;
     __shared__ double scratch[40];
@@ -612,11 +681,12 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
             return;
         }
     }
-    for (int l = tid; l < k; l += 128) gsh[l] = (l == t) ? 0.0 : red_gram(red, ldz, k, l);
+    for (int l = tid; l < k; l += 128) gsh[l] = (l == t) ? (resid_form ? -nw : 0.0) : red_gram(red, ldz, k, l);
     __syncthreads();
     const i64 j = (i64)blockIdx.x * 128 + tid;
     double x = 0.0, mx = -1.0e300;
     if (j < d) {
+        if (told) told[j] = T[(i64)t * ldt + j];
         // gsh[t] == 0, so row t may be read like the others; 16 loads are issued before the first use
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int l0 = 0; l0 < k; l0 += 16) {
@@ -672,7 +742,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
                                                      const double* __restrict__ Gpart, int nwb, double* __restrict__ red,
                                                      i64 ldz, double* __restrict__ xraw, double* __restrict__ tpart,
                                                      i64* __restrict__ tpart_idx, int check_prev, int tprev, int sweep,
-                                                     KParams p, DevState* st) {
+                                                     KParams p, DevState* st, int resid_form, double* __restrict__ told) {
     if (st->halt) return;
     const int tid = threadIdx.x;
     __shared__ double sh[32 * 33];
@@ -748,12 +818,13 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int l = l0 + 32 * q;
-                    tv[q] = (l < k && l != t) ? T[(i64)l * ldt + j] : 0.0;
+                    tv[q] = (l < k && (l != t || resid_form)) ? T[(i64)l * ldt + j] : 0.0;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int l = l0 + 32 * q;
                     if (l < k && l != t) a = fma(gsh[l], tv[q], a);
+                    else if (l == t && resid_form) a = fma(-nw, tv[q], a);   // + ||w_t||^2 T[t,:] (explicit-residual form)
                 }
             }
         sh[g * 33 + cc] = a;
@@ -765,6 +836,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
         if (tid < 32 && j < d) {
             double acc = 0.0;
             for (int q = 0; q < 32; ++q) acc += sh[q * 33 + tid];
+            if (told) told[j] = T[(i64)t * ldt + j];
             const double numer = (zs[tid] - acc) - p.reg_t_l1;
             if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
             else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
@@ -930,6 +1002,25 @@ __global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ G
             st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
         }
     }
+}
+
+// row-sharded runs: this rank's share of sum W[:,tprev] (and no negative-denominator flag) into tail[0..1]; the
+// verdict is taken on the all-reduced pair (k_wcheck_tail)
+__global__ __launch_bounds__(256) void k_colsum_tail(const double* __restrict__ Gpart, int nwb, int k,
+                                                     double* __restrict__ tail, const DevState* __restrict__ st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    double a = ordered_sum<8>(Gpart + k + 1, k + 2, threadIdx.x, nwb, (int)blockDim.x);
+    a = block_sum(a, scratch);
+    if (threadIdx.x == 0) { tail[0] = a; tail[1] = 0.0; }
+}
+
+// max-residual reset of a row-sharded run: this rank's candidate (largest row-residual norm, its GLOBAL row index)
+__global__ void k_pack_candidate(const double* __restrict__ rowpos, const i64* __restrict__ idx, i64 row_offset,
+                                 double* __restrict__ out) {
+    const i64 i = idx[0];
+    out[0] = rowpos[i];
+    out[1] = (double)(row_offset + i);
 }
 
 // =========================================================================================

@@ -1,6 +1,16 @@
 """Row-sharded RRI over the GPUs of one node: one process per GPU, X and W blocked by rows,
 T replicated.
 
+Two ways to run it:
+
+RowGroup (the product path)  the communicator lives INSIDE librri_hip.so (rri_comm_create: RCCL over xGMI, resolved
+    at run time): every rank attaches it to its handle and calls the ordinary entry points -- engine.sweep(),
+    nmf(X_rows, k, ..., group=grp) -- collectively.  A sweep is one C call; the all-reduce of a topic step is enqueued
+    on the handle's stream between two kernels, no Python and no torch per topic.
+
+ShardedRRI (below)  the same step protocol with the collective in the caller's hands (torch.distributed on a
+    caller-owned buffer): what hosts with their own collectives use, and how the protocol is tested over gloo.
+
 A topic step needs ONE cross-row reduction: [w_t^T X (d) | w_t^T W (k) | ||w_t||^2 | sum W[:,t-1]].
 Every rank reduces its shard into the engine's reduce buffer (rri_topic_reduce_local), the ranks
 all-reduce that buffer (float64; RCCL over xGMI through torch.distributed -- the payload is
@@ -22,6 +32,126 @@ def shard_rows(n, world_size, rank):
 
 PAUSED = 1
 EVENT_RESET_T, EVENT_RESET_W = 1, 2
+
+
+class RowGroup(object):
+    """The communicator of a row-sharded run and where this rank's rows sit in the global matrix.
+
+        grp = RowGroup.rccl(n_local)                  # under torchrun: id and block sizes travel over torch.distributed
+        out = nmf(X_rows, k, W_in=W_rows, T_in=T, group=grp)          # every rank, same arguments
+        grp.close()
+
+    `sizes[r]` = rows of rank r (contiguous blocks in rank order).  The RCCL communicator is created once per process
+    and group and attached to as many handles as wanted, one after the other."""
+
+    def __init__(self, comm, rank, world, sizes, keep=()):
+        self._comm, self.rank, self.world = comm, int(rank), int(world)
+        self.sizes = [int(v) for v in sizes]
+        self.row_lo = int(sum(self.sizes[:self.rank]))
+        self.n_local = self.sizes[self.rank]
+        self.n_global = int(sum(self.sizes))
+        self._keep = keep          # ctypes callbacks must outlive the communicator
+
+    @staticmethod
+    def _exchange_default():
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('RowGroup needs torch.distributed initialised (or an `exchange` function)')
+
+        def exchange(obj):                      # every rank's object, in rank order
+            out = [None] * dist.get_world_size()
+            dist.all_gather_object(out, obj)
+            return out
+        return exchange, dist.get_rank(), dist.get_world_size()
+
+    @classmethod
+    def rccl(cls, n_local, device=0, exchange=None, rank=None, world=None):
+        """RCCL communicator inside the library.  `exchange(obj) -> [obj of rank 0, ..., obj of rank world-1]` is any
+        all-gather of small Python objects the host program has (default: torch.distributed's, whatever its backend);
+        it carries the RCCL id of rank 0 and the block sizes, nothing else."""
+        import ctypes as C
+        import os
+        from . import _capi
+        if exchange is None:
+            exchange, rank, world = cls._exchange_default()
+        lib = _capi.load_library()
+        _capi.share_rccl_with_torch()
+        # one node (rendezvous on 127.0.0.1 by contract): RCCL's bootstrap socket stays on loopback whatever interface
+        # the container's hostname resolves to -- the one step of a single-rank or single-node start that depends on
+        # the box's network set-up
+        if int(os.environ.get('LOCAL_WORLD_SIZE', world)) == world:
+            os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+        ident = (C.c_uint8 * _capi.RRI_COMM_ID_BYTES)()
+        if rank == 0:
+            st = lib.rri_comm_unique_id(ident)
+            if st != _capi.RRI_OK:
+                msg = lib.rri_last_error(None)
+                raise _capi.RRIHipUnavailable('rri_comm_unique_id failed (%d): %s' % (st, msg.decode() if msg else '?'))
+        got = exchange((bytes(bytearray(ident)) if rank == 0 else None, int(n_local)))
+        ident = (C.c_uint8 * _capi.RRI_COMM_ID_BYTES)(*bytearray(got[0][0]))
+        comm = C.c_void_p()
+        st = lib.rri_comm_create(C.byref(comm), ident, int(rank), int(world), int(device))
+        if st != _capi.RRI_OK:
+            msg = lib.rri_last_error(None)
+            raise _capi.RRIHipUnavailable('rri_comm_create failed (%d): %s' % (st, msg.decode() if msg else '?'))
+        return cls(comm, rank, world, [g[1] for g in got])
+
+    @classmethod
+    def over_torch(cls, n_local, group=None):
+        """The same protocol with torch.distributed as the transport of the library's host-callback communicator
+        (rri_comm_create_host): every collective drains the stream and goes through host memory.  For tests with
+        several ranks on ONE GPU (RCCL wants one device per rank) over gloo; not a measured path."""
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _capi
+        lib = _capi.load_library()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        as_tensor = lambda ptr, count: torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(int(count),)))
+
+        def allreduce(user, buf, count):
+            try:
+                dist.all_reduce(as_tensor(buf, count), op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:  # noqa: BLE001  (the library turns a non-zero return into RRI_ERR_COMM)
+                return 1
+
+        def allgather(user, send, count, recv):
+            try:
+                out = as_tensor(recv, count * world)
+                dist.all_gather(list(out.split(int(count))), as_tensor(send, count).clone(), group=group)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        def broadcast(user, buf, count, root):
+            try:
+                dist.broadcast(as_tensor(buf, count), src=dist.get_global_rank(group, root) if group is not None else root,
+                               group=group)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        cbs = (_capi.ALLREDUCE_FN(allreduce), _capi.ALLGATHER_FN(allgather), _capi.BROADCAST_FN(broadcast))
+        comm = C.c_void_p()
+        st = lib.rri_comm_create_host(C.byref(comm), rank, world, cbs[0], cbs[1], cbs[2], None)
+        if st != _capi.RRI_OK:
+            raise RuntimeError('rri_comm_create_host failed (%d)' % st)
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(n_local), group=group)
+        return cls(comm, rank, world, sizes, keep=cbs)
+
+    def close(self):
+        if self._comm is not None and self._comm:
+            from . import _capi
+            _capi.load_library().rri_comm_destroy(self._comm)
+            self._comm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class ShardedRRI(object):

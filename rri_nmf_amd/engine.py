@@ -28,7 +28,10 @@ def _as_host(a, what):
 
 
 class RRIEngine(object):
-    def __init__(self, n, d, k, dtype=np.float32, weighted=False, device=0, stream=None):
+    def __init__(self, n, d, k, dtype=np.float32, weighted=False, device=0, stream=None, schedule='gram'):
+        """schedule (unweighted handles): 'gram' -- the residual is never formed, one read of X per topic step
+        (the reference's form, nmf.py:670-676, 728-734) -- or 'residual' -- R = X - W T is kept in HBM and every topic
+        step is one rank-one residual update pass fused with the residual products (RRI_UNWEIGHTED_RESIDUAL)"""
         self._lib = _capi.load_library()
         self.n, self.d, self.k = int(n), int(d), int(k)
         self.dtype = np.dtype(dtype)
@@ -37,13 +40,20 @@ class RRIEngine(object):
         # weighted: False | True (dense W_mat) | 'sparse' (0/1 W_mat given as a CSR pattern, upload_observed_csr)
         self.sparse = weighted == 'sparse'
         self.weighted = bool(weighted)
+        if schedule not in ('gram', 'residual'):
+            raise ValueError("schedule must be 'gram' or 'residual'")
+        if schedule == 'residual' and self.weighted:
+            raise ValueError('the weighted flavour always keeps its (masked) residual; schedule applies to unweighted handles')
+        self.schedule = schedule
         self._h = C.c_void_p()
         self.n_resets_used = 0
         self.reset_log = []
         self.fix_reset_seed = False
         self._reset_method = None
+        self.group = None
         st = self._lib.rri_create(C.byref(self._h), self.n, self.d, self.k, _NP2RRI[self.dtype],
-                                  2 if self.sparse else int(self.weighted), int(device), C.c_void_p(stream or 0))
+                                  3 if schedule == 'residual' else 2 if self.sparse else int(self.weighted), int(device),
+                                  C.c_void_p(stream or 0))
         if st != _capi.RRI_OK:
             msg = self._lib.rri_last_error(None)
             self._h = C.c_void_p()
@@ -86,7 +96,38 @@ class RRIEngine(object):
             raise ValueError(msg)
         if st == _capi.RRI_ERR_UNSUPPORTED:
             raise NotImplementedError(msg)
+        if st == _capi.RRI_ERR_COMM:
+            raise RuntimeError('collective failed: ' + msg)
         raise RuntimeError('librri_hip: status %d: %s' % (st, msg))
+
+    # ---- row-sharded runs -----------------------------------------------------------------
+    def attach_group(self, group):
+        """this handle holds rows [group.row_lo, group.row_lo + n) of the group's n_global-row problem: from here on
+        sweep(), update_*(), objective() and the reset events are collective calls (distributed.RowGroup)"""
+        if group is None:
+            self._check(self._lib.rri_attach_comm(self._h, None, 0, 0))
+            self.group = None
+            return
+        if group.n_local != self.n:
+            raise ValueError('the group registered %d rows for this rank, the handle has %d' % (group.n_local, self.n))
+        self._check(self._lib.rri_attach_comm(self._h, group._comm, group.row_lo, group.n_global))
+        self.group = group
+
+    def comm_broadcast(self, values, root=0):
+        """`values` (float64 array) of rank `root` on every rank; identity without a group"""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._lib.rri_comm_broadcast(self._h, v.ctypes.data_as(C.POINTER(C.c_double)), v.size, int(root)))
+        return v
+
+    def comm_sum(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._lib.rri_comm_allreduce_sum(self._h, v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
+        return v
+
+    def comm_stats(self):
+        r, w, n = C.c_int32(0), C.c_int32(1), C.c_int64(0)
+        self._check(self._lib.rri_comm_stats(self._h, C.byref(r), C.byref(w), C.byref(n)))
+        return int(r.value), int(w.value), int(n.value)
 
     # ---- data ---------------------------------------------------------------------------
     def upload_X(self, X):
@@ -206,6 +247,24 @@ class RRIEngine(object):
             row = C.c_int64(-1)
             self._check(self._lib.rri_apply_reset_max_resid(self._h, t, C.byref(row)))
             self.reset_log.append((ev.kind, t, int(row.value)))
+        elif self._reset_method == 'random' and self.group is not None:
+            # row-sharded: rank 0 draws T[t,:] and the WHOLE column W[:,t] with numpy's global RNG, as the reference
+            # does for the whole matrix, and broadcasts; every rank keeps its rows
+            g = self.group
+            buf = np.zeros(self.d + g.n_global)
+            if g.rank == 0:
+                if self.fix_reset_seed:
+                    np.random.seed(t + int(np.argmax(self.get_T()[t, :])))
+                trow = np.random.rand(1, self.d)
+                buf[:self.d] = (trow / trow.sum()).ravel()
+                buf[self.d:] = np.random.rand(g.n_global)
+            buf = self.comm_broadcast(buf, 0)
+            Trow = np.ascontiguousarray(buf[:self.d])
+            Wcol = np.ascontiguousarray(buf[self.d + g.row_lo:self.d + g.row_lo + self.n])
+            self._check(self._lib.rri_apply_reset_vectors(
+                self._h, t, Trow.ctypes.data_as(C.POINTER(C.c_double)),
+                Wcol.ctypes.data_as(C.POINTER(C.c_double))))
+            self.reset_log.append((ev.kind, t, -1))
         elif self._reset_method == 'random':                 # nmf.py:778-783 / :811-816
             if self.fix_reset_seed:
                 Trow_now = self.get_T()[t, :]
@@ -246,6 +305,27 @@ class RRIEngine(object):
             self._resolve_event()
             st = self._lib.rri_resume(self._h, None)
         self._check(st)
+
+    # ---- the explicit residual (schedule='residual') ------------------------------------------
+    def residual_rebuild(self):
+        """R = X - W T for the factors now on the device"""
+        self._check(self._lib.rri_residual_rebuild(self._h))
+
+    def get_residual(self, dtype=None):
+        out = np.empty((self.n, self.d), dtype=dtype or self.dtype)
+        self._check(self._lib.rri_get_residual(self._h, out.ctypes.data, self.d, _NP2RRI[out.dtype]))
+        return out
+
+    def residual_update(self, a, b, trow, wcol, a2=None, b2=None):
+        """R <- R - a b^T [- a2 b2^T]; returns (R_new @ trow, R_new.T @ wcol) of the updated stored residual"""
+        vec = lambda v, m: None if v is None else np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(m))
+        a, a2, wcol = vec(a, self.n), vec(a2, self.n), vec(wcol, self.n)
+        b, b2, trow = vec(b, self.d), vec(b2, self.d), vec(trow, self.d)
+        ptr = lambda v: None if v is None else v.ctypes.data_as(C.POINTER(C.c_double))
+        y, z = np.empty(self.n), np.empty(self.d)
+        self._check(self._lib.rri_residual_update(self._h, ptr(a), ptr(b), ptr(a2), ptr(b2), ptr(trow), ptr(wcol),
+                                                  ptr(y), ptr(z)))
+        return y, z
 
     # ---- around the loop ----------------------------------------------------------------
     def project_W_rows(self, s):

@@ -9,6 +9,13 @@ additions select the device side:
     device_init  True / False: run the products of the randomized SVD behind the NNDSVD initialisations on the
             device (initialization.randomized_svd_device) or in scikit-learn on the host; None = on the device from
             2e7 entries of X on.  Same algorithm either way.
+    group   row-sharded run over the GPUs of one node (distributed.RowGroup): X, W_in (and W_mat) are
+            THIS rank's row block, T_in is the replicated k x d factor; every rank makes the same call and gets its
+            rows of W, the common T and the global objective history.  W_in and T_in must be given.  The reference
+            has one call for the whole X (nmf.py:98-108); this is that call, made once per rank.
+    schedule  'gram' (default): the residual is never formed, X is read once per topic step; 'residual': the explicit
+            residual R = X - W T is kept in HBM and updated by rank-one terms (the form north_star names; unweighted,
+            both halves free, k >= 2).  Same results to rounding.
     sparse_pattern  weighted flavour with scipy sparse X and 0/1 sparse W_mat: keep the residual on the observed
             entries only (True), densify on the device (False); None = pattern-only below 35 % observed.
 
@@ -44,7 +51,7 @@ class TrueObjComputer(object):
     objective value; true_objective() re-evaluates it on the device."""
 
     def __init__(self, X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, Wm, wr, dtype=None, device=0,
-                 sparse_pattern=None, preprocess=None):
+                 sparse_pattern=None, preprocess=None, group=None):
         self.X, self.W, self.T = X, W, T
         self.reg_w_l2, self.reg_t_l2 = reg_w_l2, reg_t_l2
         self.reg_w_l1, self.reg_t_l1 = reg_w_l1, reg_t_l1
@@ -52,6 +59,7 @@ class TrueObjComputer(object):
         self.obj = np.inf
         self._dtype, self._device, self._sparse_pattern = dtype, device, sparse_pattern
         self._preprocess = preprocess      # device-side tf-idf / normalisation that nmf() applied to X (idf resolved)
+        self._group = group                # row-sharded: true_objective() is then a collective call
 
     def true_objective(self):
         X = self.X   # row weights, when used, are already folded into X by nmf() (nmf.py:335-338)
@@ -61,6 +69,8 @@ class TrueObjComputer(object):
         with _engine_with_problem(X, self.Wm, k, sdt, self._device, self._sparse_pattern) as eng:
             if self._preprocess is not None:
                 eng.preprocess(**self._preprocess)
+            if self._group is not None:
+                eng.attach_group(self._group)
             eng.set_W(self.W)
             eng.set_T(self.T)
             eng.set_params(reg_w_l1=self.reg_w_l1, reg_w_l2=self.reg_w_l2, reg_t_l1=self.reg_t_l1,
@@ -104,7 +114,7 @@ def _observed_csr(X, W_mat):
     return scipy.sparse.csr_matrix((vals, M.indices, M.indptr), shape=M.shape)
 
 
-def _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern=None):
+def _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern=None, schedule='gram'):
     """Engine with X and the weights on the device.  scipy sparse X / 0-1 sparse W_mat go up as CSR: onto a
     pattern-only handle (no dense n x d array at all) when X lives on the pattern and the pattern is sparse enough
     -- `sparse_pattern` True / False forces the choice --, else densified / bit-packed on the device (SURVEY.md 8f
@@ -125,7 +135,8 @@ def _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern=None):
             eng.close()
             raise
         return eng
-    eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device)
+    eng = RRIEngine(n, d, k, dtype=sdt, weighted=W_mat is not None, device=device,
+                    schedule=schedule if W_mat is None else 'gram')
     try:
         _upload_problem(eng, X, W_mat)
     except Exception:
@@ -349,7 +360,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0,
         diagnostics=[], store_gradients=False,
         ind_rows_to_store=None, eps_gauss_t=None, delta_gauss_t=None,
-        *, dtype=None, device=0, device_init=None, sparse_pattern=None, preprocess=None):
+        *, dtype=None, device=0, device_init=None, sparse_pattern=None, preprocess=None, schedule='gram', group=None):
     """Non-negative factorisation X ~ W T by rank-one residue iteration; see the module docstring and
     the reference's docstring (nmf.py:109-269) for the parameters.  Returns a dict with 'W', 'T',
     'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
@@ -361,6 +372,15 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     device; every other case preprocesses on the host.  The idf used comes back as rtv['idf']."""
     if store_gradients and not fix_T and (fix_W or k < 2):
         raise NotImplementedError('store_gradients needs both halves free and k >= 2 on the device path')
+    if group is not None:
+        # host work that would need the other ranks' rows (the SVD behind the NNDSVD start, document frequencies,
+        # per-row weights with their refit) or that decides per rank (callbacks) is not part of the sharded call
+        if _is_empty(W_in) or _is_empty(T_in):
+            raise ValueError('a row-sharded call needs W_in (this rank\'s rows) and T_in')
+        if w_row is not None or preprocess is not None or store_gradients or (eps_gauss_t and delta_gauss_t) or \
+                callable(early_stop) or schedule != 'gram':
+            raise NotImplementedError('w_row, preprocess, store_gradients, the Gaussian mechanism, early_stop callbacks '
+                                      'and schedule=\'residual\' are single-handle options')
     draw_noise = None
     if eps_gauss_t and delta_gauss_t and not fix_T:
         # Gaussian mechanism on the T-row sums (nmf.py:422-435; Dwork & Roth p. 261)
@@ -442,8 +462,12 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         raise ValueError('W_in has wrong dimensions, must be n*k')
     if not _is_empty(T_in) and np.shape(T_in) != (k, d):
         raise ValueError('T_in has wrong dimensions, must be k*d')
-    eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern)
+    if schedule == 'residual' and (W_mat is not None or fix_W or fix_T or k < 2):
+        raise NotImplementedError("schedule='residual' is the unweighted flavour with both halves free and k >= 2")
+    eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern, schedule)
     try:
+        if group is not None:
+            eng.attach_group(group)
         on_device = device_init if device_init is not None else (float(n) * d >= DEVICE_INIT_MIN_ELEMS)
         X_init = X
         if device_spec is not None:
@@ -520,7 +544,10 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
                 for f in diagnostics:
                     rtv['diagnostics'][f.__name__].append(f(X, Wh, Th))
             logger.info('\tTime: %.3fsec' % (time.time() - sweep_t0))
-            if time.time() - wall0 >= max_time:
+            out_of_time = time.time() - wall0 >= max_time
+            if group is not None:            # rank 0's clock decides for everybody
+                out_of_time = bool(eng.comm_broadcast([float(out_of_time)], 0)[0])
+            if out_of_time:
                 logger.info('STOPPING because max_time after iter %d' % iter_no)
                 break
             if compute_obj_each_iter and universal_stopping_condition(obj_history, eps_stop=eps_stop):
@@ -559,7 +586,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if compute_obj_each_iter:
         rtv['obj_history'] = obj_history
         calc = TrueObjComputer(X, W, T, reg_w_l2, reg_t_l2, reg_w_l1, reg_t_l1, W_mat, w_row,
-                               dtype=dtype, device=device, sparse_pattern=sparse_pattern, preprocess=device_spec)
+                               dtype=dtype, device=device, sparse_pattern=sparse_pattern, preprocess=device_spec, group=group)
         calc.obj = obj_history[-1] if obj_history else np.inf
         rtv['obj_calculator'] = calc
     rtv['iter_cputime'] = iter_cputime

@@ -1,0 +1,212 @@
+"""Process-group cases of the GPU suite, run as CHILD processes of the tests (tests/test_group_gpu.py):
+
+    python tests/pg_cases.py <case> <out.npz> <log file>          (RANK / WORLD_SIZE / MASTER_PORT from the environment)
+
+Why children: a process blocked inside RCCL or hipStreamSynchronize cannot be interrupted by pytest-timeout's signal
+(round 1 lost a run to such a stall without a trace).  Every child arms `faulthandler.dump_traceback_later(..., exit=True)`
+on its log file first: a stalled rendezvous, bootstrap or collective leaves the Python stacks of all threads there
+(the ctypes / torch.distributed frame it sits in) and a non-zero exit code; the parent joins with a timeout, kills the
+exact PIDs it started and puts the log's tail into the assertion message.  Logs live under gpurun_out/pg_logs/.
+"""
+import faulthandler
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+
+HANG_AFTER_S = 150
+
+
+def _problem(n, d, k, weighted, store, seed=0):
+    from rri_nmf_amd.synthetic import planted_X, scaled_init, observed_mask
+    X = planted_X(n, d, max(k, 2), seed=seed, dtype=store)
+    M = None
+    if weighted:
+        M = observed_mask(n, d, 0.3, seed=2, dtype=store)
+        X = X * M
+    W0, T0 = scaled_init(X, k, seed=1)
+    return X, M, W0, T0
+
+
+# name -> (n, d, k, sweeps, weighted, storage, nmf flags); shared with the parent, which runs the one-handle reference
+GROUP_CASES = {
+    'plain_f32': (1501, 700, 6, 3, False, 'float32', dict()),
+    'topic_model_f64': (900, 333, 5, 3, False, 'float64', dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'regularised_f64': (800, 300, 4, 3, False, 'float64', dict(reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03)),
+    'fold_in_fix_T': (1000, 400, 5, 4, False, 'float64', dict(fix_T=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'fix_W': (1000, 400, 5, 3, False, 'float64', dict(fix_W=True)),
+    'rank_one_k1': (700, 260, 1, 3, False, 'float64', dict()),
+    'weighted_f32': (1201, 515, 5, 3, True, 'float32', dict(t_row_sum=1.0, reset_topic_method=None)),
+    'weighted_f64_regs': (700, 260, 4, 3, True, 'float64', dict(t_row_sum=1.0, reset_topic_method=None, reg_w_l1=0.01, reg_t_l1=0.02)),
+    'weighted_fix_T': (700, 260, 4, 3, True, 'float64', dict(t_row_sum=1.0, reset_topic_method=None, fix_T=True)),
+    'pattern_only_f64': (1201, 515, 5, 3, 'sparse', 'float64', dict(t_row_sum=1.0, reset_topic_method=None)),
+    'resets_W_max_resid': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6)),
+    'resets_T_max_resid': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
+    'resets_W_random': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random', fix_reset_seed=True)),
+    'weighted_resets_T': (600, 200, 4, 2, True, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
+    'c4_proportions_unequal': (100003, 1000, 50, 2, False, 'float32', dict()),
+}
+
+
+def nmf_inputs(name):
+    """(X, W_mat, W0, T0, k, keyword arguments of nmf()) of a case, all rows"""
+    import scipy.sparse as sp
+    n, d, k, sweeps, weighted, store, flags = GROUP_CASES[name]
+    X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
+    kw = dict(max_iter=sweeps, eps_stop=-1, compute_obj_each_iter=True, dtype=np.dtype(store), **flags)
+    if weighted == 'sparse':
+        A = sp.csr_matrix(M)
+        A.data = np.asarray(X[M > 0], dtype=np.float64)
+        return A, sp.csr_matrix(M), W0, T0, k, kw
+    return X, M, W0, T0, k, kw
+
+
+def _init_pg(backend, **kw):
+    import datetime
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    dist.init_process_group(backend, init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank,
+                            world_size=world, timeout=datetime.timedelta(seconds=90), **kw)
+    return rank, world
+
+
+def case_group_host_transport(out, name):
+    """nmf(X_rows, ..., group=RowGroup.over_torch(...)): the library's own sharded sweep (collectives inside rri_sweep)
+    with gloo as the transport of its host-callback communicator; unequal row blocks"""
+    import torch.distributed as dist
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd.distributed import RowGroup
+    rank, world = _init_pg('gloo')
+    try:
+        X, M, W0, T0, k, kw = nmf_inputs(name)
+        n = X.shape[0]
+        cut = [0] + [int(round(n * (0.6 if world == 2 else (r + 1.0) / world))) if r < world - 1 else n for r in range(world)]
+        lo, hi = cut[rank], cut[rank + 1]
+        if rank == 1 and world == 2 and os.environ.get('RRI_TEST_SEED_OTHER_RANK'):
+            np.random.seed(12345)         # only rank 0's generator may matter for 'random' resets
+        with RowGroup.over_torch(hi - lo) as grp:
+            assert (grp.row_lo, grp.n_global) == (lo, n)
+            r = nmf_mod.nmf(X[lo:hi], k, W_mat=None if M is None else M[lo:hi], W_in=W0[lo:hi], T_in=T0, group=grp, **kw)
+            obj2 = r['obj_calculator'].true_objective()       # collective re-evaluation on a fresh handle
+        np.savez(out, W=r['W'], T=r['T'], obj=np.array(r['obj_history']), obj2=obj2, resets=r['n_resets_used'], lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+def case_group_rccl_single_rank(out):
+    """the in-library RCCL communicator with one rank (world sizes above one need one GPU per rank: the driver's run):
+    rri_comm_unique_id / rri_comm_create / rri_attach_comm, then the collective entry points"""
+    from conftest import load_golden, relfro
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd.distributed import RowGroup
+    from rri_nmf_amd.engine import RRIEngine
+    res = {}
+    exchange = lambda obj: [obj]                       # one rank: no host channel needed at all (no torch.distributed)
+    with RowGroup.rccl(1501, device=0, exchange=exchange, rank=0, world=1) as grp:
+        X, M, W0, T0 = _problem(1501, 700, 6, False, np.float32)
+        with RRIEngine(1501, 700, 6, dtype=np.float32) as e:
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+            e.sweep(3)
+            Wa, Ta, oa = e.get_W(), e.get_T(), e.objective()
+        with RRIEngine(1501, 700, 6, dtype=np.float32) as e:
+            e.attach_group(grp)
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+            e.sweep(2)
+            e.sweep(1)
+            Wb, Tb, ob = e.get_W(), e.get_T(), e.objective()
+            res['allreduce_calls'] = e.comm_stats()[2]
+        res['plain'] = [relfro(Wb, Wa), relfro(Tb, Ta), abs(ob - oa) / abs(oa)]
+    # a second group in the same process (communicators come and go with nmf() calls of a host program)
+    g = load_golden('g6_rare_branches')
+    n, d, k = [int(v) for v in g['shape']]
+    from rri_nmf_amd.synthetic import planted_X, scaled_init
+    X = planted_X(n, d, k, seed=3, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=4)
+    with RowGroup.rccl(n, device=0, exchange=exchange, rank=0, world=1) as grp:
+        for key, flags, gW, gT in (('resets_W', dict(t_row_sum=1.0, reg_w_l1=1e6), 'l1killW_mrd_W', 'l1killW_mrd_T'),
+                                   ('resets_T', dict(t_row_sum=1.0, reg_t_l1=1e6), 'l1kill_W', 'l1kill_T')):
+            r = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, eps_stop=-1, group=grp, **flags)
+            res[key] = [relfro(r['W'], g[gW]), relfro(r['T'], g[gT]), float(r['n_resets_used'])]
+        Xw, Mw, W0w, T0w = _problem(700, 260, 4, True, np.float64)
+        flags = dict(t_row_sum=1.0, reset_topic_method=None, max_iter=3, eps_stop=-1)
+        a = nmf_mod.nmf(Xw, 4, W_mat=Mw, W_in=W0w, T_in=T0w, **flags)
+        b = nmf_mod.nmf(Xw, 4, W_mat=Mw, W_in=W0w, T_in=T0w, group=grp, **flags)
+        res['weighted'] = [relfro(b['W'], a['W']), relfro(b['T'], a['T']), 0.0]
+    with open(out, 'w') as f:
+        json.dump(res, f)
+
+
+def case_legacy_protocol_single_rank_nccl(out):
+    """ShardedRRI (collective in the caller's hands: torch.distributed on the engine's stream) with a one-rank RCCL
+    group of torch's: the split step protocol equals rri_sweep, with and without reset events"""
+    import torch
+    import torch.distributed as dist
+    from conftest import load_golden, relfro
+    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
+    from rri_nmf_amd.engine import RRIEngine
+    from rri_nmf_amd.synthetic import planted_X, scaled_init
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # RCCL's bootstrap socket: loopback (see RowGroup.rccl)
+    _init_pg('nccl', device_id=torch.device('cuda', 0))
+    res = {}
+    try:
+        n, d, k = 3000, 1100, 5
+        X = planted_X(n, d, k, seed=0, dtype=np.float32)
+        W0, T0 = scaled_init(X, k, seed=1)
+        with RRIEngine(n, d, k, dtype=np.float32) as e:
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+            e.sweep(3)
+            Wa, Ta, obja = e.get_W(), e.get_T(), e.objective()
+        eng, red, stream = make_device_shard(n, d, k, dtype=np.float32, device_index=0)
+        eng.upload_X(X), eng.set_W(W0), eng.set_T(T0), eng.set_params()
+        drv = ShardedRRI(eng, red, k, stream=stream)
+        drv.sweep(2)
+        drv.sweep(1)
+        res['plain'] = [relfro(eng.get_W(), Wa), relfro(eng.get_T(), Ta), abs(drv.objective() - obja) / abs(obja)]
+        res['allreduce_calls'] = drv.allreduce_calls
+        eng.close()
+        g = load_golden('g6_rare_branches')
+        n, d, k = [int(v) for v in g['shape']]
+        X = planted_X(n, d, k, seed=3, dtype=np.float64)
+        W0, T0 = scaled_init(X, k, seed=4)
+        for key, flags, gW, gT in (('resets_W', dict(t_row_sum=1.0, reg_w_l1=1e6), 'l1killW_mrd_W', 'l1killW_mrd_T'),
+                                   ('resets_T', dict(t_row_sum=1.0, reg_t_l1=1e6), 'l1kill_W', 'l1kill_T')):
+            with RRIEngine(n, d, k, dtype=np.float64) as e:
+                e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+                e.sweep(2)
+                Wa, Ta, na = e.get_W(), e.get_T(), e.n_resets_used
+            eng, red, stream = make_device_shard(n, d, k, dtype=np.float64, device_index=0)
+            eng.upload_X(X), eng.set_W(W0), eng.set_T(T0), eng.set_params(**flags)
+            drv = ShardedRRI(eng, red, k, stream=stream, row_lo=0, n_global=n)
+            drv.sweep(1)
+            first = [relfro(eng.get_W(), g[gW]), relfro(eng.get_T(), g[gT])]
+            drv.sweep(1)
+            res[key] = first + [relfro(eng.get_W(), Wa), relfro(eng.get_T(), Ta), float(drv.n_resets_used), float(na)]
+            eng.close()
+    finally:
+        dist.destroy_process_group()
+    with open(out, 'w') as f:
+        json.dump(res, f)
+
+
+if __name__ == '__main__':
+    case, out, log = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(os.path.dirname(os.path.abspath(log)), exist_ok=True)
+    logf = open(log, 'w')
+    faulthandler.enable(file=logf, all_threads=True)
+    faulthandler.dump_traceback_later(HANG_AFTER_S, exit=True, file=logf)
+    try:
+        args = sys.argv[4:]
+        globals()['case_' + case](out, *args)
+    except BaseException:
+        import traceback
+        traceback.print_exc(file=logf)
+        logf.flush()
+        raise
+    faulthandler.cancel_dump_traceback_later()
+    logf.write('ok\n')
+    logf.close()

@@ -152,13 +152,22 @@ def test_weighted_dense_and_pattern_only_paths_agree_at_full_size(problem):
                 o.append(e.objective())
             return e.get_W(), e.get_T(), o
 
+    # the handle bench.py --config c5 times: dense fp32 residual, bit-packed mask
+    M32 = Mask.float()
+    X32 = X * M32
+    torch.cuda.synchronize()     # bound device memory must be complete: the handle's stream does not wait for torch's
+    res = {'dense32': run(lambda: RRIEngine(N, D, K, dtype=np.float32, weighted=True),
+                          lambda e: (e.bind_X_device(X32.data_ptr(), X32.stride(0)),
+                                     e.bind_mask_device(M32.data_ptr(), M32.stride(0))))}
+    del X32, M32
+    torch.cuda.empty_cache()
     M64 = Mask.double()
     X64 = X.double() * M64
     del Mask
-    torch.cuda.synchronize()     # bound device memory must be complete: the handle's stream does not wait for torch's
-    res = {'dense64': run(lambda: RRIEngine(N, D, K, dtype=np.float64, weighted=True),
-                          lambda e: (e.bind_X_device(X64.data_ptr(), X64.stride(0)),
-                                     e.bind_mask_device(M64.data_ptr(), M64.stride(0))))}
+    torch.cuda.synchronize()
+    res['dense64'] = run(lambda: RRIEngine(N, D, K, dtype=np.float64, weighted=True),
+                         lambda e: (e.bind_X_device(X64.data_ptr(), X64.stride(0)),
+                                    e.bind_mask_device(M64.data_ptr(), M64.stride(0))))
     del X64, M64
     torch.cuda.empty_cache()
     res['sparse64'] = run(lambda: RRIEngine(N, D, K, dtype=np.float64, weighted='sparse'), lambda e: e.upload_observed_csr(A))
@@ -167,8 +176,34 @@ def test_weighted_dense_and_pattern_only_paths_agree_at_full_size(problem):
     ew, et = rel(res['sparse64'][0], res['dense64'][0]), rel(res['sparse64'][1], res['dense64'][1])
     assert ew < 1e-6 and et < 1e-6, (ew, et)
     assert np.allclose(res['sparse64'][2], res['dense64'][2], rtol=1e-10)
-    assert np.allclose(res['sparse32'][2], res['dense64'][2], rtol=1e-3)
-    assert rel(res['sparse32'][0], res['dense64'][0]) < 0.2
+
+    # the masked reconstruction M .* (W T) on the 5e7 observed entries, on the device in chunks
+    rows_of = torch.from_numpy(np.repeat(np.arange(N, dtype=np.int64), np.diff(indptr))).to(X.device)
+    cols_of = torch.from_numpy(A.indices.astype(np.int64)).to(X.device)
+
+    def masked_wt(W, T):
+        Wd, Td = torch.from_numpy(W).to(X.device), torch.from_numpy(np.ascontiguousarray(T.T)).to(X.device)
+        out = torch.empty(rows_of.numel(), dtype=torch.float64, device=X.device)
+        for lo in range(0, rows_of.numel(), 4000000):
+            hi = lo + 4000000
+            out[lo:hi] = (Wd[rows_of[lo:hi]] * Td[cols_of[lo:hi]]).sum(1)
+        return out
+
+    ref_rec = masked_wt(res['dense64'][0], res['dense64'][1])
+    rec_err = {}
+    for name in ('dense32', 'sparse32', 'sparse64'):
+        rec = masked_wt(res[name][0], res[name][1])
+        rec_err[name] = float(torch.linalg.norm(rec - ref_rec) / torch.linalg.norm(ref_rec))
+    print('C5 full size after 2 sweeps, against the float64 dense handle: masked reconstruction', rec_err,
+          'W', {nm: rel(res[nm][0], res['dense64'][0]) for nm in rec_err},
+          'objective', {nm: abs(res[nm][2][-1] / res['dense64'][2][-1] - 1.0) for nm in rec_err})
+    assert rec_err['sparse64'] < 1e-7
+    # fp32 residual (the benched handles): parity is stated on the objective and the masked reconstruction -- the
+    # trajectory of W, T from this random start amplifies a 6e-8 storage rounding to percents (docstring above)
+    for name in ('dense32', 'sparse32'):
+        assert np.allclose(res[name][2], res['dense64'][2], rtol=1e-3), (name, res[name][2], res['dense64'][2])
+        assert rec_err[name] < 5e-2, (name, rec_err[name])
+        assert rel(res[name][0], res['dense64'][0]) < 0.2
     for name in res:
         o = res[name][2]
         assert all(b <= a for a, b in zip(o, o[1:])), (name, o)

@@ -1,0 +1,132 @@
+"""Row-sharded runs behind the boundary: the communicator lives in librri_hip.so and the sharded
+sweep is the ordinary rri_sweep / nmf(..., group=) call.
+
+  * two ranks on the ONE GPU of the test box, unequal row blocks, gloo as the transport of the library's host-callback
+    communicator (RCCL wants one device per rank): every flavour and flag set -- plain, topic model, regularised, fixed
+    halves (fold-in), k = 1, weighted dense / pattern-only, reset events of both kinds and both methods, and a case at
+    C4's proportions (n / d = 100, k = 50) -- against ONE handle holding all rows;
+  * one rank through RCCL itself (rri_comm_create), and the caller-owned protocol (ShardedRRI) over torch's RCCL.
+
+All process-group work runs in child processes that leave a stack trace when they stall (tests/pg_cases.py).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relfro
+
+pytestmark = pytest.mark.gpu
+CASES_PY = os.path.join(ROOT, 'tests', 'pg_cases.py')
+LOG_DIR = os.path.join(ROOT, 'gpurun_out', 'pg_logs')
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_children(case, world, tmp_path, args=(), timeout=240, env_extra=None):
+    """starts `world` ranks of tests/pg_cases.py, waits, and fails with the children's logs if one stalls or dies"""
+    os.makedirs(LOG_DIR, exist_ok=True)
+    port = _free_port()
+    procs, outs, logs = [], [], []
+    for r in range(world):
+        out = os.path.join(str(tmp_path), '%s_%s_r%d.%s' % (case, '_'.join(args), r, 'npz' if 'host_transport' in case else 'json'))
+        log = os.path.join(LOG_DIR, '%s_%s_r%d.log' % (case, '_'.join(args), r))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_PORT=str(port), MASTER_ADDR='127.0.0.1')
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, CASES_PY, case, out, log] + list(args), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs.append(out)
+        logs.append(log)
+    failed = []
+    for r, p in enumerate(procs):
+        try:
+            so, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()                      # the exact PID started above
+            so, _ = p.communicate()
+            failed.append((r, 'timeout', so))
+            continue
+        if p.returncode != 0:
+            failed.append((r, 'exit code %d' % p.returncode, so))
+    if failed:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        msg = []
+        for r, why, so in failed:
+            tail = open(logs[r]).read()[-3000:] if os.path.exists(logs[r]) else '(no log)'
+            msg.append('rank %d: %s\n--- log %s ---\n%s\n--- output ---\n%s' % (r, why, logs[r], tail, (so or '')[-1500:]))
+        pytest.fail('\n'.join(msg))
+    return outs
+
+
+@pytest.fixture(scope='module')
+def cases():
+    import pg_cases
+    return pg_cases
+
+
+def _case_names():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('pg_cases_names', CASES_PY)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return sorted(mod.GROUP_CASES)
+
+
+@pytest.mark.parametrize('name', _case_names())
+def test_two_ranks_through_nmf_equal_one_handle(name, tmp_path, cases):
+    from rri_nmf_amd import nmf as nmf_mod
+    outs = run_children('group_host_transport', 2, tmp_path, args=(name,),
+                        env_extra={'RRI_TEST_SEED_OTHER_RANK': '1'} if 'random' in name else None)
+    X, M, W0, T0, k, kw = cases.nmf_inputs(name)
+    n, d, kk, sweeps, weighted, store, flags = cases.GROUP_CASES[name]
+    if flags.get('reset_topic_method') == 'random':
+        np.random.seed(0)                   # irrelevant with fix_reset_seed, as in the reference
+    ref = nmf_mod.nmf(X, k, W_mat=M, W_in=W0, T_in=T0, **kw)
+    parts = [np.load(o) for o in outs]
+    assert int(parts[0]['lo']) == 0 and int(parts[0]['hi']) == int(parts[1]['lo']) and int(parts[1]['hi']) == n
+    assert int(parts[0]['hi']) != n - int(parts[0]['hi'])          # unequal blocks
+    W = np.vstack([p['W'] for p in parts])
+    assert np.array_equal(parts[0]['T'], parts[1]['T'])              # replicated, bit for bit
+    assert np.array_equal(parts[0]['obj'], parts[1]['obj'])          # the global objective, the same on every rank
+    # float64 storage: the order of the row sums only.  fp32 residual of the weighted flavour: the one-handle run
+    # below a launch-bound size fuses its small reductions differently and the stored residual rounds apart: 1e-4
+    tol = 1e-4 if (store == 'float32' and weighted) else 1e-9
+    assert relfro(W, ref['W']) < tol and relfro(parts[0]['T'], ref['T']) < tol, (relfro(W, ref['W']), relfro(parts[0]['T'], ref['T']))
+    assert int(parts[0]['resets']) == int(parts[1]['resets']) == ref['n_resets_used']
+    if 'resets' in name:
+        assert ref['n_resets_used'] >= kk
+    assert np.allclose(parts[0]['obj'], ref['obj_history'], rtol=max(tol, 1e-9))
+    assert abs(float(parts[0]['obj2']) - ref['obj_history'][-1]) <= max(tol, 1e-9) * abs(ref['obj_history'][-1])
+
+
+def test_one_rank_through_rccl_inside_the_library(tmp_path):
+    out, = run_children('group_rccl_single_rank', 1, tmp_path)
+    res = json.load(open(out))
+    assert max(res['plain']) < 1e-12, res['plain']
+    assert res['allreduce_calls'] >= 3 * 6              # one per topic step (+ the column verdict at the end of a call)
+    for key in ('resets_W', 'resets_T'):
+        assert res[key][0] < 2e-9 and res[key][1] < 2e-9 and res[key][2] == 6, (key, res[key])     # the reference's vectors
+    assert max(res['weighted'][:2]) < 1e-10, res['weighted']
+
+
+def test_caller_owned_protocol_over_torch_rccl_single_rank(tmp_path):
+    out, = run_children('legacy_protocol_single_rank_nccl', 1, tmp_path)
+    res = json.load(open(out))
+    assert max(res['plain']) < 1e-12, res['plain']
+    assert res['allreduce_calls'] == 3 * 5 + 1     # the second call reuses the reduction its predecessor left for topic 0
+    for key in ('resets_W', 'resets_T'):
+        w1, t1, w2, t2, nd, na = res[key]
+        assert w1 < 2e-9 and t1 < 2e-9 and w2 < 1e-12 and t2 < 1e-12 and nd == na >= 6, (key, res[key])

@@ -461,3 +461,15 @@ def test_bench_line_keeps_its_contract():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 'traffic' in r
     c = j['cpu_baseline']
     assert c['value'] > 0 and c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['unit'] == j['unit'] and c['sample']
+    assert c['one_thread']['value'] > 0 and c['one_thread']['cores'] == 1
+    # parity in the same run, at C2's FULL size: the device path against the CPU oracle after 1 and 2 sweeps (2e-9:
+    # summation order only, the bound of this file), next to the oracle's own 1-ulp sensitivity
+    ps = j['parity_sample']
+    assert ps['rows'] == 10000 and ps['sweeps'] == 2
+    for key in ('after_1_sweeps', 'after_2_sweeps'):
+        assert ps[key]['relfro_W'] < 2e-9 and ps[key]['relfro_T'] < 2e-9, (key, ps[key])
+    assert ps['reference_self_sensitivity']['relfro_W'] > 0.0          # the control measures something
+    # the explicit-residual schedule ran beside it (fp32 residual: BASELINE's 1e-4 bar against the default schedule)
+    sc = j['rank1_update']['schedule']
+    assert sc['sweeps_per_s'] > 0 and max(sc['vs_default_schedule_after_4_sweeps'].values()) < 1e-4, sc
+    assert j['rank1_update']['achieved'] > 0

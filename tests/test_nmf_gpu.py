@@ -156,48 +156,6 @@ def test_errors_raised_like_the_reference():
                     w_row_sum=1.0, reg_t_l2=-50.0)
 
 
-@pytest.mark.timeout(180)
-def test_sharded_stepping_single_rank_matches_sweep():
-    """the split step protocol (reduce -> [all-reduce] -> finish) gives what rri_sweep gives; run with a
-    one-rank RCCL group so the collective is exercised on the engine's torch stream"""
-    import datetime
-    import os
-    import socket
-    import torch
-    import torch.distributed as dist
-    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
-    from rri_nmf_amd.engine import RRIEngine
-    n, d, k = 3000, 1100, 5
-    X = planted_X(n, d, k, seed=0, dtype=np.float32)
-    W0, T0 = scaled_init(X, k, seed=1)
-    with RRIEngine(n, d, k, dtype=np.float32) as e:
-        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params()
-        e.sweep(3)
-        Wa, Ta, obja = e.get_W(), e.get_T(), e.objective()
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:      # a free port: nothing is assumed about the box
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # one node: RCCL's bootstrap socket needs no other interface
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
-                            timeout=datetime.timedelta(seconds=90), device_id=torch.device('cuda', 0))
-    try:
-        eng, red, stream = make_device_shard(n, d, k, dtype=np.float32, device_index=0)
-        eng.upload_X(X); eng.set_W(W0); eng.set_T(T0); eng.set_params()
-        drv = ShardedRRI(eng, red, k, stream=stream)
-        drv.sweep(2)
-        drv.sweep(1)
-        Wb, Tb = eng.get_W(), eng.get_T()
-        objb = drv.objective()
-        assert drv.allreduce_calls == 3 * k + 1   # the second call reuses the reduction its predecessor left for topic 0
-        eng.close()
-    finally:
-        dist.destroy_process_group()
-    # same arithmetic up to the order of the small sums: at launch-bound sizes rri_sweep fuses k_reduce and
-    # k_trow_numer into one launch (k_trow_small), the split protocol keeps them apart
-    assert relfro(Wa, Wb) < 1e-13 and relfro(Ta, Tb) < 1e-13
-    assert abs(obja - objb) <= 1e-12 * abs(obja)
-
-
 @pytest.mark.parametrize('ci', [0, 1, 2, 3])
 def test_convergence_rs_setting(ci):
     """tests/test_nmf.py:57-78: weighted NMF on the recsys fixture, objective non-increasing"""
@@ -232,50 +190,6 @@ def test_convergence_RS_Estimator():
     assert abs(E2.score(X) - float(g['rs_noes_score'])) < 1e-4
     Wnew = E2.transform(g['Xte'].astype(np.float64))
     assert Wnew.shape == (n, 5) and Wnew.min() >= 0
-
-
-@pytest.mark.timeout(180)
-def test_sharded_resets_match_single_call_path():
-    """reset events in the row-sharded stepping (resolved collectively by ShardedRRI) give what rri_sweep's own
-    pause / resolve / resume gives: W columns killed (events noticed by the next T-row step, the last one by the
-    final check) and T rows killed (events inside a topic step)"""
-    import datetime
-    import os
-    import socket
-    import torch
-    import torch.distributed as dist
-    from rri_nmf_amd.distributed import ShardedRRI, make_device_shard
-    from rri_nmf_amd.engine import RRIEngine
-    g = load_golden('g6_rare_branches')
-    n, d, k = [int(v) for v in g['shape']]
-    X = planted_X(n, d, k, seed=3, dtype=np.float64)
-    W0, T0 = scaled_init(X, k, seed=4)
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # one node: RCCL's bootstrap socket needs no other interface
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
-                            timeout=datetime.timedelta(seconds=90), device_id=torch.device('cuda', 0))
-    try:
-        for flags, gW, gT in ((dict(t_row_sum=1.0, reg_w_l1=1e6), 'l1killW_mrd_W', 'l1killW_mrd_T'),
-                              (dict(t_row_sum=1.0, reg_t_l1=1e6), 'l1kill_W', 'l1kill_T')):
-            with RRIEngine(n, d, k, dtype=np.float64) as e:
-                e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params(**flags)
-                e.sweep(2)
-                Wa, Ta, na = e.get_W(), e.get_T(), e.n_resets_used
-            eng, red, stream = make_device_shard(n, d, k, dtype=np.float64, device_index=0)
-            eng.upload_X(X); eng.set_W(W0); eng.set_T(T0); eng.set_params(**flags)
-            drv = ShardedRRI(eng, red, k, stream=stream, row_lo=0, n_global=n)
-            drv.sweep(1)
-            W1, T1 = eng.get_W(), eng.get_T()
-            assert relfro(W1, g[gW]) < TOL and relfro(T1, g[gT]) < TOL        # the reference's vectors after 1 sweep
-            drv.sweep(1)
-            Wb, Tb = eng.get_W(), eng.get_T()
-            eng.close()
-            assert drv.n_resets_used == na and na >= k
-            assert relfro(Wb, Wa) < 1e-12 and relfro(Tb, Ta) < 1e-12
-    finally:
-        dist.destroy_process_group()
 
 
 def test_sparse_inputs_are_ingested_as_csr():

@@ -23,6 +23,10 @@ for d in sys.argv[2:]:
     for kn, (cnt, tot) in acc.items():
         out[kn]['launches'] = cnt
         out[kn][name + '_KB_avg'] = tot / cnt
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # noqa: E402  (the stamp of the kernel sources this profile belongs to)
+out['_source_stamp'] = bench.source_stamp()
 json.dump(out, open(sys.argv[1], 'w'), indent=1)
+del out['_source_stamp']
 for kn, v in sorted(out.items(), key=lambda kv: -kv[1].get('FETCH_SIZE_KB_avg', 0))[:8]:
     print('%-74s %s' % (kn, {k: round(x, 1) if isinstance(x, float) else x for k, x in v.items()}))

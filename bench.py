@@ -563,7 +563,7 @@ def main():
         Xs_loc = Xs_dev[lo_s:hi_s].contiguous()
         torch.cuda.synchronize()
         if group is not None:
-            g2 = RowGroup(group._comm, rank, world, [shard_rows(rows_s, world, r)[1] - shard_rows(rows_s, world, r)[0] for r in range(world)])
+            g2 = group.resized([shard_rows(rows_s, world, r)[1] - shard_rows(rows_s, world, r)[0] for r in range(world)])
             e5 = RRIEngine(hi_s - lo_s, d, k, dtype=np.float32, device=local_rank)
             e5.attach_group(g2)
             e5.bind_X_device(Xs_loc.data_ptr(), Xs_loc.stride(0))

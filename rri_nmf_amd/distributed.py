@@ -141,7 +141,16 @@ class RowGroup(object):
         dist.all_gather_object(sizes, int(n_local), group=group)
         return cls(comm, rank, world, sizes, keep=cbs)
 
+    def resized(self, sizes):
+        """the same communicator for another problem: `sizes[r]` rows on rank r (the caller makes sure every rank passes
+        the same list).  The view does not own the communicator: close the group it came from."""
+        view = RowGroup(self._comm, self.rank, self.world, sizes, keep=self._keep)
+        view._owner = False
+        return view
+
     def close(self):
+        if not getattr(self, '_owner', True):
+            return
         if self._comm is not None and self._comm:
             from . import _capi
             _capi.load_library().rri_comm_destroy(self._comm)

@@ -49,7 +49,7 @@ GROUP_CASES = {
     'resets_T_max_resid': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
     'resets_W_random': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random', fix_reset_seed=True)),
     'weighted_resets_T': (600, 200, 4, 2, True, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
-    'c4_proportions_unequal': (100003, 1000, 50, 2, False, 'float32', dict()),
+    'c4_proportions_unequal': (100003, 1000, 50, 1, False, 'float32', dict()),
 }
 
 
@@ -135,7 +135,7 @@ def case_group_rccl_single_rank(out):
         Xw, Mw, W0w, T0w = _problem(700, 260, 4, True, np.float64)
         flags = dict(t_row_sum=1.0, reset_topic_method=None, max_iter=3, eps_stop=-1)
         a = nmf_mod.nmf(Xw, 4, W_mat=Mw, W_in=W0w, T_in=T0w, **flags)
-        b = nmf_mod.nmf(Xw, 4, W_mat=Mw, W_in=W0w, T_in=T0w, group=grp, **flags)
+        b = nmf_mod.nmf(Xw, 4, W_mat=Mw, W_in=W0w, T_in=T0w, group=grp.resized([700]), **flags)
         res['weighted'] = [relfro(b['W'], a['W']), relfro(b['T'], a['T']), 0.0]
     with open(out, 'w') as f:
         json.dump(res, f)

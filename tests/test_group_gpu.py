@@ -104,12 +104,29 @@ def test_two_ranks_through_nmf_equal_one_handle(name, tmp_path, cases):
     # float64 storage: the order of the row sums only.  fp32 residual of the weighted flavour: the one-handle run
     # below a launch-bound size fuses its small reductions differently and the stored residual rounds apart: 1e-4
     tol = 1e-4 if (store == 'float32' and weighted) else 1e-9
+    if name == 'c4_proportions_unequal':
+        # k = 50 dependent topic steps from a random start amplify a rounding difference (here: the order of the row
+        # sums, two shards against one) far more than the small cases do.  Measured, not assumed: the CPU oracle against
+        # itself with every entry of W0 moved by one ulp, same sweeps, bounds what two correct implementations can show
+        from oracle import rri_oracle as orc
+        X64 = np.asarray(X, dtype=np.float64)
+        Wa, Ta = W0.astype(np.float64).copy(), T0.astype(np.float64).copy()
+        Wb, Tb = np.nextafter(Wa, np.inf), Ta.copy()
+        orc.plain_sweeps(X64, Wa, Ta, sweeps)
+        orc.plain_sweeps(X64, Wb, Tb, sweeps)
+        sens = max(relfro(Wb, Wa), relfro(Tb, Ta))
+        assert sens > 1e-9, sens                       # the control measures something at this size
+        tol = 20 * sens
+        assert relfro(np.vstack([p['W'] for p in parts]), Wa) < tol and relfro(ref['W'], Wa) < tol     # both against the oracle
     assert relfro(W, ref['W']) < tol and relfro(parts[0]['T'], ref['T']) < tol, (relfro(W, ref['W']), relfro(parts[0]['T'], ref['T']))
     assert int(parts[0]['resets']) == int(parts[1]['resets']) == ref['n_resets_used']
     if 'resets' in name:
         assert ref['n_resets_used'] >= kk
     assert np.allclose(parts[0]['obj'], ref['obj_history'], rtol=max(tol, 1e-9))
-    assert abs(float(parts[0]['obj2']) - ref['obj_history'][-1]) <= max(tol, 1e-9) * abs(ref['obj_history'][-1])
+    # rtv['obj_calculator'].true_objective(): a collective re-evaluation for the RETURNED factors (after the final
+    # projection of W, nmf.py:519-529), on a fresh handle
+    want = ref['obj_calculator'].true_objective()
+    assert abs(float(parts[0]['obj2']) - want) <= max(tol, 1e-9) * abs(want)
 
 
 def test_one_rank_through_rccl_inside_the_library(tmp_path):

@@ -51,6 +51,23 @@ __device__ __forceinline__ double ordered_sum(const double* __restrict__ p, long
     return a;
 }
 
+// the same, continuing a sum already begun (a0): the terms are still added one by one in index order
+template <int B>
+__device__ __forceinline__ double ordered_sum_acc(double a0, const double* __restrict__ p, long long stride, int i0, int i1, int step) {
+    double a = a0;
+    for (int i = i0; i < i1; i += step * B) {
+        double v[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+            const int ii = i + q * step;
+            v[q] = ii < i1 ? p[(long long)ii * stride] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < B; ++q) a += v[q];
+    }
+    return a;
+}
+
 template <typename S>
 __device__ __forceinline__ S wave_sum(S v) {
     v += dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
@@ -79,6 +96,25 @@ __device__ __forceinline__ double wave_rowsum8(const double (&v)[8], double* til
     s += dpp<0xB1, 0xf>(s);      // quad_perm [1,0,3,2]
     s += dpp<0x4E, 0xf>(s);      // quad_perm [2,3,0,1]
     s += dpp<0x141, 0xf>(s);     // row_half_mirror: the other quad of the 8-lane group
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+
+// The same reduction in two steps, so that the 8 partials need not be live in registers at once: row u's partial is
+// parked as soon as it is complete (park), the transposed read and the adds follow after the 8th (finish).  Same
+// operations in the same order as wave_rowsum8: bit-identical sums.
+__device__ __forceinline__ void wave_rowsum8_park(double* tile, int u, int lane, double v) {
+    tile[u * 72 + lane + (lane >> 3)] = v;
+}
+__device__ __forceinline__ double wave_rowsum8_finish(double* tile, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int r = lane >> 3, p = lane & 7;
+    const double* src = tile + r * 72 + p * 9;
+    double s = ((src[0] + src[1]) + (src[2] + src[3])) + ((src[4] + src[5]) + (src[6] + src[7]));
+    s += dpp<0xB1, 0xf>(s);
+    s += dpp<0x4E, 0xf>(s);
+    s += dpp<0x141, 0xf>(s);
     __builtin_amdgcn_wave_barrier();
     return s;
 }

@@ -185,6 +185,11 @@ struct rri_ctx {
     DevState* st = nullptr;
 
     int npanels = 1, rpb = 1, nrb = 1, nwb = 1, ntb = 1;
+    int gpart_n = 1;   // rows of Gpart its last writer left (k_wcol: nwb, k_wcol_resid: nwb256, fused pass: nrb)
+    int ttpart_n = 0;  // partial vectors T T[t]^T in Ttpart (k_tgram: nsplit; k_trow_small for the fused W update: ntb32)
+    int ttpart_topic = -1;   // topic whose k_trow_small left them (the fused W update needs them fresh)
+    int xy_rows = 0;   // blocks per topic in XYpart (stride xy_stride)
+    int xy_stride = 1;
     int ntb32 = 1;     // 32-column blocks of k_trow_small
     int tpart_n = 1;   // entries the last T-row step left in tpart (128- or 32-column blocks)
 
@@ -389,7 +394,10 @@ struct TimedScope {
 
 // ---- typed launch helpers ------------------------------------------------------------------
 // geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
-int g_pass_unroll = 8, g_pass_nt = 1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8)
+int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8).  nt: -1 = per handle (non-temporal
+                                                        // loads where X cannot stay in the caches, plain loads where it can)
+int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
+int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
 int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
@@ -398,36 +406,71 @@ int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two lau
 int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
                              // interleaved up to 1024 workgroups (+2 % at 20000 x 5000; -1 % at C3, where it stays off)
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
+int g_fuse_w = 0;       // RRI_FUSE_W=1: the W-column update in the epilogue of the pass where a workgroup sees whole rows (two
+                        // launches per topic step instead of three).  Measured at 10000 x 1000, k = 20: 1865 against 1937 sweeps/s --
+                        // the epilogue is as long as the launch it saves (profiles/r02_c2_variants.log).  Off by default.
 
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
 template <typename SX>
 struct LaunchX {
     typedef SX Elem;
     // row-dot slots of the 4 waves, the active W column, (UPD: one or two arrays of rank-one row factors,) the row-sum tiles
-    static size_t pass_shmem(const rri_ctx* c, int upd) { return ((5 + upd) * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double); }
+    static size_t pass_shmem(const rri_ctx* c, int upd, bool fw = false) {
+        // fused W-column update: T T[t]^T (k) and its partials (ntb32 k), the Gram partial (k + 2), the row dots (rpb), the
+        // block's rows of W (k rpb)
+        return ((5 + upd + (fw ? 1 : 0)) * (size_t)c->rpb + 4 * 8 * 72 +
+                (fw ? 2 * (size_t)c->k + 2 + (size_t)c->ntb32 * c->k + (size_t)c->k * c->rpb + 256 : 0)) * sizeof(double);
+    }
     // the rank-one terms a pass folds into the residual before it takes its products (UPD = 1: a, b; UPD = 2: also a2 and
     // b2 - b2sub)
     struct Upd {
         const double *a = nullptr, *b = nullptr, *a2 = nullptr, *b2 = nullptr, *b2sub = nullptr;
     };
-    template <bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS>
-    static void pass_k(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u, const TgramJob& job) {
+    // Non-temporal loads keep a streamed X from washing W, T and the partial sums out of the caches -- where X cannot
+    // stay there anyway.  A matrix that fits the 256 MB Infinity Cache is re-read from it by every pass: plain loads are
+    // 4 % faster at 10000 x 1000 (2020 against 1937 sweeps/s, profiles/r02_c2_variants.log).
+    static bool pass_nt(const rri_ctx* c) {
+        if (g_pass_nt >= 0) return g_pass_nt != 0;
+        return (double)c->n * (double)c->LD * (double)c->es > 192.0e6;
+    }
+    template <bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS, bool FW = false>
+    static void pass_k(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u, const TgramJob& job,
+                       const FuseW& fw = FuseW{}) {
         const int ncols = (int)std::min<i64>(ldp, c->LD);
         typedef typename std::conditional<(UPD > 0), SX, const SX>::type XT;
-        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
-                           pass_shmem(c, UPD), c->stream, (XT*)Xp, ldp, (int)c->n, ncols, trow, wc, c->Ypart,
+        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS, FW>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
+                           pass_shmem(c, UPD, FW), c->stream, (XT*)Xp, ldp, (int)c->n, ncols, trow, wc, c->Ypart,
                            c->Zpart, c->LD, c->rpb, c->npanels, u.a, u.b, u.a2, u.b2, u.b2sub, (const DevState*)c->st, job,
-                           (g_pass_interleave == 1 || (g_pass_interleave < 0 && c->npanels * c->nrb <= 1024)) ? c->nrb : 0);
+                           // interleaved row chunks: the workgroups running at one time walk ONE window of the matrix, as a
+                           // linear stream does.  Read-only pass: +2 % up to 1024 workgroups, nothing at C3.  Read-modify-write
+                           // (UPD): +4-9 % at C3 (profiles/r02_residual_schedule_geometry.log) -- reads and writes of a window
+                           // stay in the DRAM pages that are open
+                           (g_pass_interleave == 1 || (g_pass_interleave < 0 && (c->npanels * c->nrb <= 1024 || UPD > 0))) ? c->nrb : 0, fw);
+    }
+    // the pass of topic t with the W-column update of t and the Gram partials of tn in its epilogue (FuseW)
+    static void pass_fused(rri_ctx* c, int t, int tn, const FuseW& fw) {
+        TimedScope ts(c, 0);
+        const double* trow = c->T + (i64)t * c->LD;
+        const double* wc = c->W + (i64)tn * c->ldw;
+        if (pass_nt(c)) pass_k<true, true, 0, 8, true, true, true>(c, c->X, c->ldx, trow, wc, Upd{}, TgramJob{}, fw);
+        else pass_k<true, true, 0, 8, false, true, true>(c, c->X, c->ldx, trow, wc, Upd{}, TgramJob{}, fw);
     }
     template <bool DO_Y, bool DO_Z, int UPD>
     static void pass_cfg(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u = Upd{},
                          const TgramJob& job = TgramJob{}) {
+        if (UPD > 0 && g_pass_unroll_upd == 16) {
+            // the read-modify-write variants: 16 rows in flight per wave, row dots by DPP wave sums -- 0.665 against 0.639
+            // of 8 TB/s for the 8-row LDS row-sum variant at C3 (profiles/r02_residual_schedule_geometry.log)
+            if (pass_nt(c)) pass_k<DO_Y, DO_Z, UPD, 16, true, false>(c, Xp, ldp, trow, wc, u, job);
+            else pass_k<DO_Y, DO_Z, UPD, 16, false, false>(c, Xp, ldp, trow, wc, u, job);
+            return;
+        }
         if (g_pass_unroll == 8 && g_pass_rs && DO_Y) {
-            if (g_pass_nt) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, ldp, trow, wc, u, job);
+            if (pass_nt(c)) pass_k<DO_Y, DO_Z, UPD, 8, true, true>(c, Xp, ldp, trow, wc, u, job);
             else pass_k<DO_Y, DO_Z, UPD, 8, false, true>(c, Xp, ldp, trow, wc, u, job);
             return;
         }
-        const int key = g_pass_unroll * 2 + (g_pass_nt ? 1 : 0);
+        const int key = g_pass_unroll * 2 + (pass_nt(c) ? 1 : 0);
         switch (key) {
 #define RRI_CASE(U_)                                                                              \
     case U_ * 2 + 0: pass_k<DO_Y, DO_Z, UPD, U_, false, false>(c, Xp, ldp, trow, wc, u, job); break;   \
@@ -466,7 +509,9 @@ struct LaunchX {
                            dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
                            (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
                            wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
-                           (const DevState*)c->st);
+                           (const DevState*)c->st,
+                           // interleaved row chunks for the passes that write E back (read-modify-write), as for k_pass<UPD>
+                           (g_wpass_il == 1 || (g_wpass_il < 0 && (WRITE || c->npanels * c->nrb <= 1024))) ? c->nrb : 0);
     }
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
     static void wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
@@ -691,25 +736,31 @@ struct LaunchX {
 
 struct LK {  // float64-only kernels
     // rows of Gpart a column update leaves: one per 64-row tile (k_wcol) or per 256-row block (k_wcol_resid)
-    static int gpart_rows(const rri_ctx* c) { return c->explicit_resid ? c->nwb256 : c->nwb; }
+    static int gpart_rows(const rri_ctx* c) { return c->gpart_n; }
     template <bool UPDATE>
     static void wcol_resid(rri_ctx* c, int t, int tn, int sweep) {
         TimedScope ts(c, 1);
         hipLaunchKernelGGL((k_wcol_resid<UPDATE>), dim3(c->nwb256), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n,
                            c->k, t, tn, (const double*)c->Ypart, c->npanels, (const double*)c->Ttpart, c->nsplit,
                            c->dwv, c->Gpart, sweep, kparams(c), c->st);
+        c->gpart_n = c->nwb256;
     }
     static size_t wcol_shmem(const rri_ctx* c) { return (size_t)(2 * c->k + 2 + 256 + 64) * sizeof(double); }
     template <bool UPDATE, bool CARRY>
     static void wcol_src(rri_ctx* c, int t, int tn, int sweep, const double* ypart, int nslices) {
         TimedScope ts(c, 1);
         hipLaunchKernelGGL((k_wcol<UPDATE, CARRY>), dim3(c->nwb), dim3(256), wcol_shmem(c), c->stream, c->W, c->ldw,
-                           (int)c->n, c->k, t, tn, ypart, nslices, (const double*)c->Ttpart, c->nsplit, c->Gpart,
-                           c->XYpart + (i64)t * c->nwb * WCOL_TILES, sweep, kparams(c), c->st);
-        if (UPDATE) {
-            c->xy_run = (t == 0) ? 1 : (c->xy_run == t ? t + 1 : -1);
-            c->xy_valid = c->xy_run == c->k;
-        }
+                           (int)c->n, c->k, t, tn, ypart, nslices, (const double*)c->Ttpart, c->ttpart_n, c->Gpart,
+                           c->XYpart + (i64)t * c->xy_stride, sweep, kparams(c), c->st);
+        c->gpart_n = c->nwb;
+        if (UPDATE) note_xy(c, t, c->nwb * WCOL_TILES);
+    }
+    // the cross terms <w_t, X t_t> of topic t were left in XYpart as `rows` block partials: the objective after the
+    // sweep needs all k topics in order, written with the same block count
+    static void note_xy(rri_ctx* c, int t, int rows) {
+        if (t == 0) { c->xy_run = 1; c->xy_rows = rows; }
+        else c->xy_run = (c->xy_run == t && c->xy_rows == rows) ? t + 1 : -1;
+        c->xy_valid = c->xy_run == c->k;
     }
     template <bool UPDATE, bool CARRY>
     static void wcol(rri_ctx* c, int t, int tn, int sweep) {
@@ -733,11 +784,12 @@ struct LK {  // float64-only kernels
     static bool small(const rri_ctx* c) {
         return g_trow_small && (double)gpart_rows(c) * (c->k + 2) * c->ntb32 <= 4.0e6;
     }
-    static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
+    static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final, bool leave_ttp = false) {
         hipLaunchKernelGGL(k_trow_small, dim3(c->ntb32), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->Zpart, c->nrb, (const double*)c->Gpart, gpart_rows(c), c->red, c->LD, c->xraw,
                            c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st, c->explicit_resid ? 1 : 0,
-                           c->explicit_resid ? c->told : (double*)nullptr);
+                           c->explicit_resid ? c->told : (double*)nullptr, leave_ttp ? c->Ttpart : (double*)nullptr);
+        if (leave_ttp) { c->ttpart_n = c->ntb32; c->ttpart_topic = t; }
         c->tpart_n = c->ntb32;
         trow_final_if_needed(c, t, sweep, force_final);
     }
@@ -751,6 +803,8 @@ struct LK {  // float64-only kernels
                            sweep, pos, kparams(c), c->st);
     }
     static void tgram(rri_ctx* c, int t, int finish, int sweep) {
+        c->ttpart_n = c->nsplit;
+        c->ttpart_topic = -1;
         hipLaunchKernelGGL(k_tgram, dim3(c->k, c->nsplit), dim3(256), 0, c->stream, (const double*)c->T, c->LD,
                            (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n, finish, sweep,
                            kparams(c), c->st);
@@ -874,6 +928,7 @@ rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int
 }
 
 void invalidate(rri_ctx* c) {
+    c->ttpart_topic = -1;
     c->carry_valid = false;
     c->carry_topic = -1;
     c->resid_valid = false;
@@ -925,13 +980,22 @@ void enqueue_prologue(rri_ctx* c, int t, int sweep) {
     c->carry_topic = t;
 }
 
+// Launch-bound sizes where one workgroup of the pass sees whole rows (d <= 1024 fp32 columns): the W-column update
+// and the Gram partials of the next topic run in the epilogue of the pass (FuseW) -- two launches per topic step
+// (k_trow_small, k_pass) instead of three.  Needs the T row final when k_trow_small ends (no projection configured).
+bool fused_w_ok(const rri_ctx* c) {
+    return g_fuse_w && !c->weighted && !c->explicit_resid && !c->comm && c->npanels == 1 && c->k >= 2 && LK::light(c) &&
+           !c->prm.fix_W && !c->prm.fix_T && LK::small(c) && g_pass_unroll == 8 && g_pass_rs && g_side_jobs &&
+           (i64)c->ntb32 * c->k <= 256 * FW_NPRE && (i64)c->k * c->rpb <= 256 * FW_NPRE && c->ntb32 <= 256;   // what the epilogue prefetches
+}
+
 void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     if (!c->carry_valid || c->carry_topic != t) enqueue_prologue(c, t, sweep);
     {
         TimedScope ts(c, 2);
         const int chk = c->pending_wcheck ? 1 : 0;
         if (LK::small(c) && !c->comm) {
-            LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
+            LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone, fused_w_ok(c) && !standalone);
         } else {
             // the one cross-row reduction of a topic step: [w_t^T X | slices of (w_t^T W, ||w_t||^2, sum W[:,t-1])];
             // row-sharded, the ranks all-reduce it here, on the stream, between the two kernels
@@ -954,6 +1018,22 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int tn = (t + 1) % k;
     // T T[t,:]^T for k_wcol; the T-row checks ride along only when a T half of this topic just ran and left its sums.
     // Where a pass follows, the job joins its grid (no launch of its own); with T fixed there is no pass.
+    if (carry_next && fused_w_ok(c) && c->ttpart_topic == t && !c->skip_row_finish) {
+        // the T half of this topic has just run and left T T[t]^T and the row sums: pass + W-column update + Gram
+        // partials of the next topic as ONE launch
+        const FuseW fw{c->W, c->ldw, k, t, tn, (const double*)c->Ttpart, c->ttpart_n, (const double*)c->tpart, c->tpart_n,
+                       c->Gpart, c->XYpart + (i64)t * c->xy_stride, sweep, kparams(c), c->st};
+        DISPATCH(c, L::pass_fused(c, t, tn, fw));
+        c->gpart_n = c->nrb;
+        LK::note_xy(c, t, c->nrb);
+        c->ttpart_topic = -1;
+        c->carry_valid = true;
+        c->carry_topic = tn;
+        c->pending_wcheck = true;
+        c->pending_wcheck_topic = t;
+        c->resid_valid = false;
+        return;
+    }
     const int finish = (LK::light(c) && !c->prm.fix_T && !c->skip_row_finish) ? 1 : 0;
     c->skip_row_finish = false;
     TgramJob job{};
@@ -963,6 +1043,8 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     } else {
         job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n,
                        c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
+        c->ttpart_n = c->nsplit;
+        c->ttpart_topic = -1;
     }
     if (carry_next) {
         DISPATCH(c, (L::template pass<true, true>(c, t, tn, job)));
@@ -1053,6 +1135,8 @@ void enqueue_rW_half(rri_ctx* c, int sweep, int t) {
     } else {
         job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n,
                        c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
+        c->ttpart_n = c->nsplit;
+        c->ttpart_topic = -1;
     }
     const double* trow = c->T + (i64)t * c->LD;
     DISPATCH(c, {
@@ -1341,8 +1425,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->kp = (int)round_up(k, 8);
     c->es = dtype == RRI_F32 ? 4 : 8;
     c->VN = (int)(16 / c->es);
-    if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) g_pass_unroll = v; }
-    if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0;
+    if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
+    if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_IL")) g_pass_interleave = atoi(e) != 0 ? 1 : 0;
@@ -1350,6 +1434,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_GRAPH")) g_graph = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
+    if (const char* e = getenv("RRI_FUSE_W")) g_fuse_w = atoi(e) != 0;
+    if (const char* e = getenv("RRI_WPASS_IL")) g_wpass_il = atoi(e) != 0 ? 1 : 0;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
 #define CR(call)                                                                                   \
@@ -1381,10 +1467,15 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         const int nrb_t = std::max(1, std::max(1, atoi(e)) / c->npanels);
         rpb = (n + nrb_t - 1) / nrb_t;
     } else {
-        for (int total = 2048; total >= 512 && rpb == 0; total -= 512) {
+        // handles whose passes write a residual back (explicit-residual, dense weighted): the read-modify-write pass
+        // likes ~8192 workgroups of >= 96 rows (+3 % at C3 for the residual schedule, +6 % for the weighted one)
+        const bool rmw = explicit_resid || weighted == RRI_WEIGHTED_DENSE;
+        const int total_max = rmw ? 8192 : 2048;
+        const i64 rows_min = rmw ? 96 : 192;
+        for (int total = total_max; total >= 512 && rpb == 0; total -= 512) {
             const int nrb_t = std::max(1, total / c->npanels);
             const i64 r = (n + nrb_t - 1) / nrb_t;
-            if (r >= 192 || total == 512) rpb = r;
+            if (r >= rows_min || total == 512) rpb = r;
         }
     }
     rpb = std::max<i64>(rpb, rpb_min);
@@ -1425,17 +1516,22 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMemsetAsync(c->Ypart, 0, (size_t)c->npanels * n * f8, c->stream));
     CR(hipMalloc((void**)&c->Zpart, (size_t)c->nrb * c->LD * f8));
     CR(hipMemsetAsync(c->Zpart, 0, (size_t)c->nrb * c->LD * f8, c->stream));
-    CR(hipMalloc((void**)&c->Gpart, (size_t)c->nwb * (k + 2) * sizeof(double)));
-    CR(hipMemsetAsync(c->Gpart, 0, (size_t)c->nwb * (k + 2) * sizeof(double), c->stream));
-    CR(hipMalloc((void**)&c->XYpart, (size_t)k * c->nwb * WCOL_TILES * f8));
-    CR(hipMemsetAsync(c->XYpart, 0, (size_t)k * c->nwb * WCOL_TILES * f8, c->stream));
+    const size_t grows = (size_t)std::max(c->nwb, c->nrb);      // k_wcol leaves a row per 64-row tile, the fused pass one per row block
+    c->gpart_n = c->nwb;
+    c->xy_stride = (int)std::max<size_t>(grows, (size_t)c->nwb * WCOL_TILES);
+    CR(hipMalloc((void**)&c->Gpart, grows * (k + 2) * sizeof(double)));
+    CR(hipMemsetAsync(c->Gpart, 0, grows * (k + 2) * sizeof(double), c->stream));
+    CR(hipMalloc((void**)&c->XYpart, (size_t)k * c->xy_stride * f8));
+    CR(hipMemsetAsync(c->XYpart, 0, (size_t)k * c->xy_stride * f8, c->stream));
     CR(hipMalloc((void**)&c->red, (size_t)c->red_elems * f8));
     CR(hipMemsetAsync(c->red, 0, (size_t)c->red_elems * f8, c->stream));
     c->own_red = true;
     CR(hipMalloc((void**)&c->xraw, (size_t)c->LD * f8));
     CR(hipMemsetAsync(c->xraw, 0, (size_t)c->LD * f8, c->stream));
-    CR(hipMalloc((void**)&c->Ttpart, (size_t)c->nsplit * k * f8));
-    CR(hipMemsetAsync(c->Ttpart, 0, (size_t)c->nsplit * k * f8, c->stream));
+    const size_t ttn = (size_t)std::max(c->nsplit, c->ntb32);   // k_tgram: nsplit column slices; k_trow_small: one per 32 columns
+    c->ttpart_n = c->nsplit;
+    CR(hipMalloc((void**)&c->Ttpart, ttn * k * f8));
+    CR(hipMemsetAsync(c->Ttpart, 0, ttn * k * f8, c->stream));
     CR(hipMalloc((void**)&c->Qt, (size_t)k * c->ldw * f8));
     const size_t ntp = (size_t)std::max(c->ntb, c->ntb32);
     CR(hipMalloc((void**)&c->tpart, ntp * sizeof(double)));
@@ -2139,7 +2235,7 @@ static rri_status objective_terms(rri_ctx* c, double out[3], double* tn) {
         double* xy = gt + k * k;
         hipLaunchKernelGGL(k_gram, dim3(k, k), dim3(256), 0, c->stream, (const double*)c->W, c->ldw, c->n, k, gw);
         hipLaunchKernelGGL(k_gram, dim3(k, k), dim3(256), 0, c->stream, (const double*)c->T, c->LD, c->d, k, gt);
-        hipLaunchKernelGGL(k_rows_sum, dim3(k), dim3(256), 0, c->stream, (const double*)c->XYpart, c->nwb * WCOL_TILES, xy);
+        hipLaunchKernelGGL(k_rows_sum, dim3(k), dim3(256), 0, c->stream, (const double*)c->XYpart, c->xy_rows, c->xy_stride, xy);
         // ||.||^2 are the traces of the Gram matrices; the 1-norms are only needed with an l1 penalty
         const bool need_l1 = c->prm.reg_w_l1 != 0.0 || c->prm.reg_t_l1 != 0.0 || !tn;
         double hw[256 * 3], ht[256 * 3];

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                                                const double* __restrict__ a2v, const double* __restrict__ b2v,
                                                double* __restrict__ Ypart, double* __restrict__ Y2part,
                                                double* __restrict__ Zpart, double* __restrict__ Z2part, i64 ldz,
-                                               int rpb, int npg, const DevState* __restrict__ st) {
+                                               int rpb, int npg, const DevState* __restrict__ st, int nrb_il) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
@@ -137,12 +137,18 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* tile = a2sh + rpb + wave * (8 * 72);     // [4][8*72] private row-sum tiles (RS)
     const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
-    const int row0 = rb * rpb, row1 = min(n, row0 + rpb);
+    // rows of this block, local index li -> global row: contiguous (rb rpb + li), or -- nrb_il > 0 -- chunk q of U rows is
+    // chunk q nrb + rb of the matrix, so the workgroups running at one time walk ONE window of E as a linear stream does
+    // (what made the read-modify-write pass of the unweighted residual schedule 4-9 % faster, k_pass)
+    auto grow = [&](int li) -> int {
+        return nrb_il > 0 ? ((li / U) * nrb_il + rb) * U + (li % U) : rb * rpb + li;
+    };
     const int col = (pg * 4 + wave) * PW + lane * VN;
-    for (int i = threadIdx.x; i < row1 - row0; i += 256) {
-        if (DO_Z) wsh[i] = wcol[row0 + i];
-        a1sh[i] = a1v[row0 + i];
-        if (UPD2) a2sh[i] = a2v[row0 + i];
+    for (int i = threadIdx.x; i < rpb; i += 256) {
+        const int g = grow(i);
+        if (DO_Z) wsh[i] = g < n ? wcol[g] : 0.0;
+        a1sh[i] = g < n ? a1v[g] : 0.0;
+        if (UPD2) a2sh[i] = g < n ? a2v[g] : 0.0;
     }
     __syncthreads();
     const bool ok = col < ncols;
@@ -157,9 +163,22 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
         b2[e] = (UPD2 && ok) ? b2v[col + e] : 0.0;
     }
     if (wave_has_cols) {
-        for (int r = row0; r < row1; r += U) {
+        for (int l0 = 0; l0 < rpb; l0 += U) {
+            const int r = grow(l0);                  // the U rows of a chunk are consecutive, r a multiple of U
+            if (r >= n) break;
+            const int row1 = n;
+            const int row0 = r - l0;                 // so that (rr - row0) below is the local index l0 + u
             V x[U];
             typename MaskLoad<SX, MBITS>::Raw mk[U];
+            // bit-packed mask: the U rows of a chunk (U = 4 or 8, r a multiple of U) lie in ONE word per lane -- one
+            // load per chunk.  (Loaded row by row, as the array form below must be, the same word was requested U times:
+            // as many vector-memory instructions again as the residual itself takes, PMC SQ_INSTS_VMEM_RD 8.1e6 against
+            // 4.1e6 for k_pass on the same bytes -- profiles/r02_pmc_sq_c5_before_mask_word_fix.txt.)
+            unsigned mword = 0u;
+            if constexpr (MBITS) {
+                static_assert(U == 4 || U == 8, "a chunk of rows must lie inside one 8-row mask word");
+                if (ok) mword = Mb[(i64)(r >> 3) * ldb + (col >> 2)] >> (col & 3);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rr = r + u;
@@ -167,7 +186,8 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 mk[u] = MaskLoad<SX, MBITS>::zero();
                 if (rr < row1 && ok) {
                     x[u] = stream_load<NT>(reinterpret_cast<const V*>(E + (i64)rr * ldx + col));
-                    mk[u] = MaskLoad<SX, MBITS>::load(M, ldm, Mb, ldb, rr, col);
+                    if constexpr (MBITS) mk[u] = mword >> ((rr & 7) << 2);
+                    else mk[u] = MaskLoad<SX, MBITS>::load(M, ldm, Mb, ldb, rr, col);
                 }
             }
             double ys[U], y2s[U];
@@ -210,14 +230,14 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 const double t1 = wave_rowsum8(reinterpret_cast<const double (&)[8]>(ys), tile, lane);
                 const double t2 = wave_rowsum8(reinterpret_cast<const double (&)[8]>(y2s), tile, lane);
                 const int rr = r + (lane >> 3);
-                if ((lane & 7) == 0 && rr < row1) { ysh[wave * rpb + rr - row0] = t1; y2sh[wave * rpb + rr - row0] = t2; }
+                if ((lane & 7) == 0) { ysh[wave * rpb + rr - row0] = (rr < row1) ? t1 : 0.0; y2sh[wave * rpb + rr - row0] = (rr < row1) ? t2 : 0.0; }
             } else if (DO_Y) {
                 double yv = ys[0], y2v = y2s[0];
 #pragma unroll
                 for (int u = 1; u < U; ++u)
                     if (lane == u) { yv = ys[u]; y2v = y2s[u]; }
                 const int rr = r + lane;
-                if (lane < U && rr < row1) { ysh[wave * rpb + rr - row0] = yv; y2sh[wave * rpb + rr - row0] = y2v; }
+                if (lane < U) { ysh[wave * rpb + rr - row0] = (rr < row1) ? yv : 0.0; y2sh[wave * rpb + rr - row0] = (rr < row1) ? y2v : 0.0; }
             }
         }
         if (DO_Z && ok) {
@@ -228,13 +248,16 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
             }
         }
     } else if (DO_Y) {
-        for (int i = lane; i < row1 - row0; i += 64) { ysh[wave * rpb + i] = 0.0; y2sh[wave * rpb + i] = 0.0; }
+        for (int i = lane; i < rpb; i += 64) { ysh[wave * rpb + i] = 0.0; y2sh[wave * rpb + i] = 0.0; }
     }
     if (DO_Y) {
         __syncthreads();
-        for (int i = threadIdx.x; i < row1 - row0; i += 256) {
-            Ypart[(i64)pg * n + row0 + i] = (ysh[i] + ysh[rpb + i]) + (ysh[2 * rpb + i] + ysh[3 * rpb + i]);
-            Y2part[(i64)pg * n + row0 + i] = (y2sh[i] + y2sh[rpb + i]) + (y2sh[2 * rpb + i] + y2sh[3 * rpb + i]);
+        for (int i = threadIdx.x; i < rpb; i += 256) {
+            const int g = grow(i);
+            if (g < n) {
+                Ypart[(i64)pg * n + g] = (ysh[i] + ysh[rpb + i]) + (ysh[2 * rpb + i] + ysh[3 * rpb + i]);
+                Y2part[(i64)pg * n + g] = (y2sh[i] + y2sh[rpb + i]) + (y2sh[2 * rpb + i] + y2sh[3 * rpb + i]);
+            }
         }
     }
 }

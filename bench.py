@@ -319,16 +319,19 @@ def main():
     mask_packed = weighted and os.environ.get('RRI_MASK_BITS', '1') != '0'
     arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else (2.0 if resid_sched else 1.0)
     bytes_per_launch = float(n_local) * d * es * arrays_per_launch
+    sp_merge = os.environ.get('RRI_SP_MERGE', '1') != '0'
+    sp_step_bytes = (2.0 * (2.0 + 2.0 * es)) if sp_merge else (6.0 + 5.0 * es)     # fp32: 20 B (26 B with the dense flavour's schedule)
     if sparse:
-        # per topic step and observed entry: pass B reads (uint16 offset, fp32 value) of the row copy = 6 B; pass C
-        # reads and rewrites both copies = 2 x (2 + 4 + 4) B; two timed passes per step -> 13 B per entry and pass on
-        # average (the factor tables, staged in LDS once per workgroup, are not counted)
-        bytes_per_launch = (6.0 + 5.0 * es) / 2.0 * nnz   # fp32: 13 B
+        # per topic step and observed entry: ONE read-modify-write pass over each of the two copies of the pattern
+        # residual, (uint16 offset + value read, value written) = 2 + 4 + 4 B each at fp32 -> 20 B per step, 10 B per
+        # timed launch (the factor tables, staged in LDS once per workgroup, are not counted).  RRI_SP_MERGE=0: the
+        # schedule shared with the dense flavour, a read pass (6 B) and two read-modify-write passes: 26 B, 13 per pass
+        bytes_per_launch = sp_step_bytes / 2.0 * nnz
     achieved = bytes_per_launch / (pass_avg_ms * 1e-3) / 1e9 if launches else 0.0
     sweeps_per_s = args.steps / elapsed
     shards = (n_global / float(cfg['n'])) if cfg['scaling'] == 'weak' else 1.0
     value = sweeps_per_s * shards
-    sweep_bytes = ((6.0 + 5.0 * es) * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es)
+    sweep_bytes = (sp_step_bytes * k * nnz if sparse else (2.0 if not weighted else 4.0) * k * n_local * d * es)
 
     out = {
         'metric': 'RRI sweeps/sec and achieved HBM GB/s on dense X (n x d, rank k)',
@@ -349,8 +352,8 @@ def main():
                                    % (world, (2 * d + 2) if weighted else (d + 8 * (k + 2)), collective)) if sharded else 'single GPU'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                     'kernel': ('k_sp_blk<float,...> passes B (row copy: read) and C (row + column copies: read, write), '
-                                'averaged; %d observed entries' % nnz if sparse else
+                     'kernel': ('k_sp_blk<float,...>: one read-modify-write pass per topic step over the row copy (both pending rank-one '
+                                'terms, row products) and one over the column copy (column sums), averaged; %d observed entries' % nnz if sparse else
                                 'k_wpass<float,...> passes B (read E, mask) and C (read E, mask; write E), averaged; mask '
                                 + ('bit-packed' if mask_packed else 'fp32') if weighted
                                 else 'k_pass<float,Y,Z,UPD=2> (rank-one residual update R <- R - a b^T - a2 b2^T, read + write, fused '
@@ -359,7 +362,7 @@ def main():
                      'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},
         'sweep_level': {'global_sweeps_per_s': sweeps_per_s,
                         'timed_launch_samples': launches,
-                        'survey_formula': ('26*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' if sparse
+                        'survey_formula': ('%d*k*nnz B per sweep (sparse-index formulation; NOT the dense 4*k*n*d*4 figure)' % int(sp_step_bytes) if sparse
                                            else '4*k*n*d*4 B per sweep (dense fp32 mask, residual not rewritten)' if weighted
                                            else '2*k*n*d*4 B per sweep (two BLAS2 passes per topic step, or one read + one write of R)'),
                         'algorithmic_GBps_2knd': sweep_bytes * sweeps_per_s / 1e9,

@@ -397,6 +397,7 @@ struct TimedScope {
 int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8).  nt: -1 = per handle (non-temporal
                                                         // loads where X cannot stay in the caches, plain loads where it can)
 int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
+int g_sp_merge = 1;      // RRI_SP_MERGE=0: pattern-only handles run the dense flavour's schedule (row copy: read pass + write pass)
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
@@ -1166,6 +1167,7 @@ void w_refresh(rri_ctx* c) {
     c->resid_valid = true;
     c->resid_fresh = true;
     c->dt_pending = false;     // the rebuilt E contains the current T
+    c->dw_pending = false;     // ... and W (pattern-only handles: the row copy's pending column change)
     c->carry_valid = false;
 }
 
@@ -1202,7 +1204,11 @@ void enqueue_wT_solve(rri_ctx* c, int sweep, int t) {
     c->carry_valid = false;
     c->resid_fresh = false;
     c->dt_pending = true;
-    if (c->prm.fix_W) {   // no W half follows: fold dt into E now, then rescale the kept column (nmf.py:450-452)
+    if (c->prm.fix_W && c->dw_pending) {   // a column change still pending on the row copy and no W half to fold it: rebuild
+        c->resid_valid = false;
+        c->dt_pending = false;
+        if (no_regs(c)) LK::scale_wcol(c, t);
+    } else if (c->prm.fix_W) {   // no W half follows: fold dt into E now, then rescale the kept column (nmf.py:450-452)
         DISPATCH(c, (L::template wpass<false, false, false, true>(c, nullptr, nullptr, wt_t, c->dtv, nullptr, nullptr)));
         c->dt_pending = false;
         if (no_regs(c)) LK::scale_wcol(c, t);
@@ -1237,7 +1243,21 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     const double* b1 = (c->prm.fix_T || !c->dt_pending) ? c->zeros : c->dtv;
     c->dt_pending = false;
     c->resid_fresh = false;
-    DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->W + (i64)t * c->ldw, b1, nullptr, nullptr)));
+    const bool sp_merged = c->sparse && g_sp_merge;
+    if (sp_merged) {
+        // Pattern-only handles keep two copies of the residual, and each copy serves ONE kind of sum: rows -> row
+        // products, columns -> column sums.  So the row copy need not be current between its own passes: the W-column
+        // change of a topic step (dw t^T) is folded into it by the row pass of the NEXT step, together with that step's
+        // T-row change -- ONE read-modify-write pass per copy and topic step (20 B per observed entry) where the
+        // schedule shared with the dense flavour takes a read pass and a read-modify-write pass over the row copy
+        // (26 B).  The copies then differ by storage roundings only (each term is still applied exactly once to each).
+        const double* a2 = c->dw_pending ? c->dwv : c->zeros;          // dw of the previous step: k_wwcol below overwrites it
+        const double* b2 = c->T + (i64)(c->dw_pending ? c->dw_topic : t) * c->LD;
+        TimedScope ts(c, 3);
+        DISPATCH(c, (L::template sp_blk<true, true, true>(c, 0, b1, b2, trow, c->W + (i64)t * c->ldw, a2, c->Ypart, c->Y2part, c->n)));
+    } else {
+        DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->W + (i64)t * c->ldw, b1, nullptr, nullptr)));
+    }
     {
         TimedScope ts(c, 1);
         hipLaunchKernelGGL(k_wwcol, dim3(c->nwb256), dim3(256), 0, c->stream, c->W, c->ldw, (int)c->n, k, t,
@@ -1246,7 +1266,13 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     }
     const bool carry_next = (k > 1) && !c->prm.fix_T;
     const double* wn = c->W + (i64)tn * c->ldw;
-    if (carry_next) DISPATCH(c, (L::template wpass<false, true, true, true>(c, nullptr, wn, c->wold, b1, c->dwv, trow)));
+    if (sp_merged) {
+        TimedScope ts(c, 3);          // the column copy: both terms of this step, the column sums of the next topic
+        if (carry_next) DISPATCH(c, (L::template sp_blk<true, true, true>(c, 1, c->wold, c->dwv, wn, b1, trow, c->Zpart, c->Z2part, c->LD)));
+        else DISPATCH(c, (L::template sp_blk<false, true, true>(c, 1, c->wold, c->dwv, wn, b1, trow, c->Zpart, c->Z2part, c->LD)));
+        c->dw_pending = true;
+        c->dw_topic = t;
+    } else if (carry_next) DISPATCH(c, (L::template wpass<false, true, true, true>(c, nullptr, wn, c->wold, b1, c->dwv, trow)));
     else DISPATCH(c, (L::template wpass<false, false, true, true>(c, nullptr, nullptr, c->wold, b1, c->dwv, trow)));
     int ns = sweep, np = t + 1;
     if (np == k) { np = 0; ns = sweep + 1; }
@@ -1436,6 +1462,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     if (const char* e = getenv("RRI_FUSE_W")) g_fuse_w = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_IL")) g_wpass_il = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("RRI_SP_MERGE")) g_sp_merge = atoi(e) != 0;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
 #define CR(call)                                                                                   \
@@ -2213,6 +2240,7 @@ static rri_status objective_terms(rri_ctx* c, double out[3], double* tn) {
         c->resid_valid = true;
         c->resid_fresh = true;
         c->dt_pending = false;
+        c->dw_pending = false;
         c->carry_valid = false;
     } else if (c->xy_valid && !g_obj_direct) {
         // 1/2 ||X - W T||^2 = 1/2 ||X||^2 - sum_t <w_t, X t_t> + 1/2 <W^T W, T T^T>: the cross terms were left by

@@ -1,0 +1,11 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 300 python -m pytest tests/test_sparse_wrri_gpu.py tests/test_sharded_gpu.py tests/test_full_size_gpu.py -m gpu -q --no-header -rf -p no:cacheprovider -k "sparse or pattern or weighted" > gpurun_out/r02_t9.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02_t9.log; tail -3 gpurun_out/r02_t9.log
+show() { python - "$1" "$2" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+r = j['roofline']
+print('%-34s %.2f sweeps/s  kernel %.4f ms %.0f GB/s (%.3f)  %s  %s' % (sys.argv[1], j['value'], r['avg_ms'], r['achieved'], r['frac'], {k: round(1e3*v, 2) for k, v in j['sweep_level']['kernel_avg_ms'].items()}, {k: ('%.2e' % v) for k, v in j.get('parity_sample', {}).items() if isinstance(v, float)}))
+PY
+}
+for rep in 1 2; do timeout -k 10 300 python bench.py --config c5s --steps 20 > /tmp/b.json 2>/tmp/b.err && show "c5s (fp32 fma terms)" /tmp/b.json || tail -5 /tmp/b.err; done

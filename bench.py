@@ -98,7 +98,8 @@ def source_stamp():
     h = hashlib.sha256()
     cs = os.path.join(ROOT, 'rri_nmf_amd', 'csrc')
     for f in sorted(os.listdir(cs)):
-        h.update(open(os.path.join(cs, f), 'rb').read())
+        if f.endswith(('.hip', '.hpp')):
+            h.update(open(os.path.join(cs, f), 'rb').read())
     return h.hexdigest()[:16]
 
 

@@ -7,7 +7,8 @@
 #   profiles/r02_bench_<tag>.json                   the bench line of the same command, taken last (so it carries the traffic)
 tag=$1; shift
 repo=$PWD
-mkdir -p $repo/profiles $repo/gpurun_out
+out=$repo/gpurun_out/profiles_r02   # only gpurun_out/ comes back from the GPU box: copy into profiles/ afterwards
+mkdir -p $out $repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$tag
 echo "[$tag] kernel stats $(date +%T)" >> $repo/gpurun_out/profile_progress.log
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$tag/st -o st -- python3 $repo/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline > /tmp/pf_$tag.st.log 2>&1
@@ -17,7 +18,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 cd $repo
 f=$(find /tmp/pf_$tag/st -name '*kernel_stats.csv' | head -1)
-python3 - "$f" "profiles/r02_${tag}_rocprofv3_kernel_stats.csv" <<'PY'
+python3 - "$f" "$out/r02_${tag}_rocprofv3_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.reader(open(sys.argv[1])))
 with open(sys.argv[2], 'w', newline='') as out:
@@ -25,8 +26,10 @@ with open(sys.argv[2], 'w', newline='') as out:
     for r in rows[:16]:
         w.writerow([r[0][:120]] + r[1:])
 PY
-python3 tools/pmc_summary.py profiles/r02_pmc_hbm_traffic_$tag.json $(dirname $(find /tmp/pf_$tag/FETCH_SIZE -name '*counter_collection.csv' | head -1)) $(dirname $(find /tmp/pf_$tag/WRITE_SIZE -name '*counter_collection.csv' | head -1)) > /tmp/pf_$tag.pmc.txt 2>&1
+python3 tools/pmc_summary.py $out/r02_pmc_hbm_traffic_$tag.json $(dirname $(find /tmp/pf_$tag/FETCH_SIZE -name '*counter_collection.csv' | head -1)) $(dirname $(find /tmp/pf_$tag/WRITE_SIZE -name '*counter_collection.csv' | head -1)) > $out/r02_pmc_hbm_traffic_$tag.txt 2>&1
+cp $out/r02_pmc_hbm_traffic_$tag.json profiles/ 2>/dev/null   # so that the bench line below finds it
 echo "[$tag] bench $(date +%T)" >> $repo/gpurun_out/profile_progress.log
-timeout -k 10 400 python3 bench.py "$@" > /tmp/pf_$tag.json 2>/tmp/pf_$tag.err && tail -1 /tmp/pf_$tag.json > profiles/r02_bench_$tag.json
+timeout -k 10 400 python3 bench.py "$@" > /tmp/pf_$tag.json 2>/tmp/pf_$tag.err && tail -1 /tmp/pf_$tag.json > $out/r02_bench_$tag.json
+tail -3 /tmp/pf_$tag.FETCH_SIZE.log > $out/r02_${tag}_pmc_fetch_tail.log; tail -3 /tmp/pf_$tag.err >> $out/r02_${tag}_pmc_fetch_tail.log
 echo "[$tag] done $(date +%T)" >> $repo/gpurun_out/profile_progress.log
-head -4 profiles/r02_${tag}_rocprofv3_kernel_stats.csv | cut -c1-160
+head -4 $out/r02_${tag}_rocprofv3_kernel_stats.csv | cut -c1-160

@@ -359,3 +359,25 @@ def test_dropin_alias_resolves_the_imports_of_the_reference_test_file():
              'try:\n    import rri_nmf_amd.dropin\nexcept ImportError as e:\n    print("refused")\n')
     res = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, cwd=ROOT, timeout=120)
     assert res.returncode == 0 and res.stdout.strip() == 'refused', res.stderr[-1500:]
+
+
+def test_row_sharded_call_is_checked_before_any_device_work():
+    """nmf(..., group=): what a sharded call cannot take is refused on the host, before a handle exists"""
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd.distributed import RowGroup, shard_rows
+    X = np.random.RandomState(0).rand(12, 7)
+    W0, T0 = np.random.RandomState(1).rand(12, 3), np.random.RandomState(2).rand(3, 7)
+    grp = RowGroup(None, 1, 3, [12, 12, 10])
+    assert (grp.row_lo, grp.n_local, grp.n_global) == (12, 12, 34)
+    view = grp.resized([5, 6, 7])
+    assert (view.row_lo, view.n_local, view.n_global) == (5, 6, 18)
+    view.close(), grp.close()                                     # a view never destroys the communicator; None is nothing to destroy
+    assert [shard_rows(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    with pytest.raises(ValueError, match='W_in'):
+        nmf_mod.nmf(X, 3, group=grp)
+    for kw in (dict(w_row=np.ones((12, 1))), dict(preprocess='normalize'), dict(store_gradients=True),
+               dict(eps_gauss_t=1.0, delta_gauss_t=0.1), dict(early_stop=lambda X, W, T: 0.0), dict(schedule='residual')):
+        with pytest.raises(NotImplementedError):
+            nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, group=grp, **kw)
+    with pytest.raises(NotImplementedError):
+        nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, fix_T=True, schedule='residual')

@@ -426,13 +426,20 @@ def test_the_abi_from_plain_c(tmp_path):
     from rri_nmf_amd import _capi
     libdir = os.path.dirname(_capi.LIB_PATH)
     exe = str(tmp_path / 'abi_smoke')
-    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+    subprocess.run(['gcc', '-std=c99', '-pthread', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
                     os.path.join(ROOT, 'tests', 'c', 'abi_smoke.c'), '-o', exe, '-L', libdir, '-lrri_hip', '-lm',
                     '-Wl,-rpath,' + libdir], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    tag, o0, o1, cw, ct = r.stdout.split()
+    lines = r.stdout.strip().splitlines()
+    tag, o0, o1, cw, ct = lines[0].split()
     assert tag == 'ok' and float(o1) < 0.2 * float(o0) and float(cw) > 0 and float(ct) > 0
+    # two row blocks on two handles in the one C process, collectives inside rri_sweep: the one-handle factors
+    tag, ew, et = lines[1].split()
+    assert tag == 'sharded' and float(ew) < 1e-9 and float(et) < 1e-9, lines[1]
+    # R <- R - a b^T on an explicit-residual handle: at most one fp32 ulp from the same arithmetic in C, products 1e-12
+    tag, ulps, ey = lines[2].split()
+    assert tag == 'residual' and float(ulps) <= 1.01 and float(ey) < 1e-12, lines[2]
 
 
 def test_bench_line_keeps_its_contract():

@@ -552,24 +552,27 @@ def main():
                                                  'costs x_upload_ms = %.1f sweeps; never part of `value`' % (bytes_per_launch / (h2d * 1e9) * sweeps_per_s)}
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value'] if out['cpu_baseline']['value'] else None
     if sharded and world > 1 and not weighted and not args.no_cpu_baseline:
-        # N > 1: (i) the CPU restatement on rank 0's shard as a stand-alone problem (same work per sweep as the shard's
-        # share); (ii) parity THROUGH the N-rank path: a small global problem (20000 x d, same k), row-sharded over the
-        # same ranks and collective, against the CPU oracle on all its rows -- every rank takes part, rank 0 reports
-        rows_s = 20000
+        # N > 1: parity THROUGH the N-rank path and the CPU baseline from ONE host run.  A problem of the workload's own
+        # shape (min(n, 100000) x d, same k, same generator) is row-sharded over the same ranks and communicator, two sweeps;
+        # rank 0 runs the CPU oracle on ALL its rows (timed: that is the baseline) and compares its block of W and the
+        # replicated T.  Every rank takes part in the sharded run.
+        rows_s = min(cfg['n'], 100000)
         Xs_dev = device_planted_shard(rows_s, d, k, seed=77, device=device)          # the same matrix on every rank
         lo_s, hi_s = shard_rows(rows_s, world, rank)
-        as_ = (float(Xs_dev.sum(dtype=torch.float64)) / (float(rows_s) * d) / k) ** 0.5
+        xsum = torch.zeros((), dtype=torch.float64, device=device)
+        for lo_ in range(0, rows_s, 100000):
+            xsum += Xs_dev[lo_:lo_ + 100000].sum(dtype=torch.float64)
+        as_ = (float(xsum) / (float(rows_s) * d) / k) ** 0.5
         gs = torch.Generator(device=device)
         gs.manual_seed(5)
         Ws0 = (as_ * torch.rand(rows_s, k, device=device, generator=gs, dtype=torch.float64)).cpu().numpy()
         Ts0 = (as_ * torch.rand(k, d, device=device, generator=gs, dtype=torch.float64)).cpu().numpy()
         torch.cuda.synchronize()
-        Xs_loc = Xs_dev[lo_s:hi_s].contiguous()
-        torch.cuda.synchronize()
+        Xs_loc = Xs_dev[lo_s:hi_s]
+        sizes_s = [shard_rows(rows_s, world, r)[1] - shard_rows(rows_s, world, r)[0] for r in range(world)]
         if group is not None:
-            g2 = group.resized([shard_rows(rows_s, world, r)[1] - shard_rows(rows_s, world, r)[0] for r in range(world)])
             e5 = RRIEngine(hi_s - lo_s, d, k, dtype=np.float32, device=local_rank)
-            e5.attach_group(g2)
+            e5.attach_group(group.resized(sizes_s))
             e5.bind_X_device(Xs_loc.data_ptr(), Xs_loc.stride(0))
             e5.set_W(Ws0[lo_s:hi_s]), e5.set_T(Ts0), e5.set_params()
             e5.sweep(2)
@@ -583,18 +586,19 @@ def main():
         if rank == 0:
             times, facs, _ = cpu_plain(Xs_dev, Ws0, Ts0, rows_s, 2, thr, rows_s)
             Wc, Tc = facs[-1]
-            out['parity_sample'] = {'what': 'a %d x %d, k=%d problem row-sharded over the same %d ranks and collective, rank 0\'s rows of W and '
-                                            'the replicated T against the CPU oracle on all rows' % (rows_s, d, k, world),
+            out['parity_sample'] = {'what': 'a %d x %d, k=%d problem (the workload\'s generator) row-sharded over the same %d ranks and collective: rank '
+                                            '0\'s rows of W and the replicated T against the CPU oracle on all rows' % (rows_s, d, k, world),
                                     'sweeps': 2, 'rows': rows_s, 'relfro_W': relfro(Wg5, Wc[lo_s:hi_s]), 'relfro_T': relfro(Tg5, Tc)}
-            rows = min(n_local, 100000)
-            times, _, _ = cpu_plain(X, W0, T0, rows, 1, thr, n_local, want_factors=False)
-            shard_rate = (1.0 / times[0]) * rows / float(n_local)     # sweeps/s of ONE n_local-row shard on these host cores
+            rate_s = len(times) / sum(times)                          # sweeps/s of a rows_s-row problem on this host
+            shard_rate = rate_s * rows_s / float(n_local)             # ... of ONE n_local-row shard
             out['cpu_baseline'] = dict(value=shard_rate * (1.0 if cfg['scaling'] == 'weak' else 1.0 / world), unit='sweeps/s', cores=thr, kind='port',
-                                       sample='rank 0\'s shard as a stand-alone problem: first %d of its %d rows, 1 timed sweep (%.2f s), numpy float64 on %d '
-                                              'threads; in the unit of `value` ONE host like this one does %s' % (
-                                                  rows, n_local, times[0], thr, 'this many shard-sweeps per second (the job has %d shards)' % world
+                                       sample='the %d x %d problem above, ALL its rows, 2 timed sweeps (%s s), numpy float64 on %d threads (%.3f sweeps/s), '
+                                              'times %.4g (rows / rows of a shard); in the unit of `value` ONE host like this one does %s' % (
+                                                  rows_s, d, ', '.join('%.2f' % t for t in times), thr, rate_s, rows_s / float(n_local),
+                                                  'this many shard-sweeps per second (the job has %d shards)' % world
                                                   if cfg['scaling'] == 'weak' else 'the whole %d-row problem at this rate (shard rate / %d)' % (n_global, world)))
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+        del Xs_dev
     eng.close()
     if group is not None:
         group.close()

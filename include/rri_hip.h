@@ -227,7 +227,7 @@ rri_status rri_comm_destroy(rri_comm* comm);     /* after every handle it was at
 /* comm == NULL detaches.  row_offset: global index of the handle's first row. */
 rri_status rri_attach_comm(rri_ctx* ctx, rri_comm* comm, int64_t row_offset, int64_t n_global);
 /* small host-side collectives for the host driver (the vectors of a 'random' reset drawn on rank 0, nmf.py:778-783;
- * stop decisions): no-ops on a handle without a communicator.  allreduce_sum: at most 8 values. */
+ * stop decisions; the d x m panels of a row-sharded randomized SVD): no-ops on a handle without a communicator. */
 rri_status rri_comm_broadcast(rri_ctx* ctx, double* host, int64_t count, int32_t root);
 rri_status rri_comm_allreduce_sum(rri_ctx* ctx, double* host, int64_t count);
 rri_status rri_comm_stats(rri_ctx* ctx, int32_t* rank, int32_t* world, int64_t* allreduce_calls);

@@ -2853,7 +2853,15 @@ rri_status rri_comm_allreduce_sum(rri_ctx* c, double* host, int64_t count) {
     CHECK_CTX(c);
     if (!host || count < 1) return fail(c, RRI_ERR_INVALID, "bad all-reduce arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    return comm_allreduce_host(c, host, count);
+    if (count <= 8 || !c->comm) return comm_allreduce_host(c, host, count);
+    DevTmp buf;                                        // larger host arrays (the d x m panels of a row-sharded start)
+    HIPCHK(c, buf.alloc((size_t)count * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(buf.p, host, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    comm_allreduce(c, (double*)buf.p, count);
+    HIPCHK(c, hipMemcpyAsync(host, buf.p, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_status != RRI_OK) { const rri_status r = c->comm_status; c->comm_status = RRI_OK; return r; }
+    return RRI_OK;
 }
 
 rri_status rri_comm_stats(rri_ctx* c, int32_t* rank, int32_t* world, int64_t* allreduce_calls) {

@@ -54,6 +54,67 @@ def randomized_svd_device(engine, n_components, random_state=None, n_oversamples
     return U[:, :k], s[:k], Vt[:k, :]
 
 
+def _cholqr2(Y, comm_sum):
+    """Orthonormal basis of the range of a tall matrix whose rows are spread over the ranks: Cholesky-QR, twice
+    (Y^T Y is all-reduced, R = chol, Y <- Y R^-1; the second round repairs the conditioning the first one squares).
+    Returns this rank's rows of Q."""
+    from scipy import linalg
+    for _ in range(2):
+        G = comm_sum(Y.T @ Y)
+        G = 0.5 * (G + G.T)
+        try:
+            R = linalg.cholesky(G, lower=False, check_finite=False)
+        except linalg.LinAlgError:       # numerically rank-deficient panel: a relative ridge keeps the factor usable
+            R = linalg.cholesky(G + 1e-13 * np.trace(G) / G.shape[0] * np.eye(G.shape[0]), lower=False, check_finite=False)
+        Y = linalg.solve_triangular(R, Y.T, trans='T', lower=False, check_finite=False).T
+    return Y
+
+
+def randomized_svd_sharded(engine, n_components, random_state=None, n_oversamples=10, n_iter='auto'):
+    """randomized_svd_device for an X whose rows are spread over the ranks of engine.group (n_global >= d): the same
+    algorithm -- same Gaussian test matrix on every rank, the same power iterations -- with
+      X Q      row-local (every rank its rows of the n x m result),
+      X^T Y    a sum over the ranks: all-reduced d x m panel (replicated afterwards),
+    the d x m factorisations replicated (the LU of scikit-learn), and the TALL n x m ones -- which scikit-learn
+    normalises by LU and finally by QR -- replaced by Cholesky-QR on the all-reduced m x m Gram matrix: another basis of
+    the same range, so U, S, V are the same up to rounding (tests: 1e-7 against the one-handle start).
+    Returns this rank's rows of U, S, V (replicated)."""
+    from scipy import linalg
+    g = engine.group
+    n, d = g.n_global, engine.d
+    if n < d:
+        raise NotImplementedError('row-sharded start: n_global < d is not built (shard the transpose, or pass W_in / T_in)')
+    comm_sum = lambda A: engine.comm_sum(np.ascontiguousarray(A).ravel()).reshape(A.shape)
+    rng = check_random_state(random_state)
+    m = n_components + n_oversamples
+    if n_iter == 'auto':
+        n_iter = 7 if n_components < 0.1 * min(n, d) else 4
+    Q = rng.normal(size=(d, m))                                   # replicated: every rank draws the same numbers
+    lu = lambda Y: linalg.lu(Y, permute_l=True, check_finite=False)[0]
+    tall = (lambda Y: _cholqr2(Y, comm_sum)) if n_iter > 2 else (lambda Y: Y)
+    wide = lu if n_iter > 2 else (lambda Y: Y)
+    for _ in range(n_iter):
+        Y = tall(engine.X_times(Q))                               # rows of X Q, normalised across the ranks
+        Q = wide(comm_sum(engine.Xt_times(Y)))                    # X^T Y, replicated
+    Qt = _cholqr2(engine.X_times(Q), comm_sum)                    # orthonormal basis of range(X Q): this rank's rows
+    B = comm_sum(engine.Xt_times(Qt)).T                           # Q^T X, m x d, replicated
+    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver='gesdd')
+    U = Qt @ Uhat
+    # svd_flip(U, Vt): the entry of largest magnitude of every column of U -- over ALL rows -- becomes positive
+    loc = np.argmax(np.abs(U), axis=0)
+    cand = np.zeros((g.world, 2, U.shape[1]))
+    cand[g.rank, 0] = np.abs(U[loc, np.arange(U.shape[1])])
+    cand[g.rank, 1] = np.sign(U[loc, np.arange(U.shape[1])])
+    cand = comm_sum(cand)
+    win = np.argmax(cand[:, 0, :], axis=0)                        # first rank on ties = lowest global row, as np.argmax
+    signs = cand[win, 1, np.arange(U.shape[1])]
+    signs[signs == 0] = 1.0
+    U = U * signs[np.newaxis, :]
+    Vt = Vt * signs[:, np.newaxis]
+    k = n_components
+    return U[:, :k], s[:k], Vt[:k, :]
+
+
 def _split_pos_neg(v):
     return np.maximum(v, 0), np.abs(np.minimum(v, 0))
 
@@ -61,13 +122,17 @@ def _split_pos_neg(v):
 _VECTORISED_FROM = 1 << 20   # n * k from which the NNDSVD factors are formed for all topics at once
 
 
-def _nndsvd_factors_vectorised(U, S, V):
+def _nndsvd_factors_vectorised(U, S, V, comm_sum=None):
     """The loop of initialization.py:109-140 for all topics at once: the same quantities, summed by numpy's
     reductions instead of one strided BLAS dot per topic (0.37 s -> 0.05 s at 100000 x 50; the per-topic loop is
-    kept for small problems, where its bits are the reference's)."""
+    kept for small problems, where its bits are the reference's).  comm_sum: U holds this rank's rows only -- the
+    squared norms of its columns are sums over the ranks."""
     Up, Un = np.maximum(U, 0), np.maximum(-U, 0)
     Vp, Vn = np.maximum(V, 0), np.maximum(-V, 0)
-    nup, nun = np.sqrt(np.einsum('ij,ij->j', Up, Up)), np.sqrt(np.einsum('ij,ij->j', Un, Un))
+    sq = np.stack([np.einsum('ij,ij->j', Up, Up), np.einsum('ij,ij->j', Un, Un)])
+    if comm_sum is not None:
+        sq = comm_sum(sq)
+    nup, nun = np.sqrt(sq[0]), np.sqrt(sq[1])
     nvp, nvn = np.sqrt(np.einsum('ij,ij->i', Vp, Vp)), np.sqrt(np.einsum('ij,ij->i', Vn, Vn))
     pos = nup * nvp > nun * nvn
     with np.errstate(divide='ignore', invalid='ignore'):
@@ -84,7 +149,12 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, row_
                    n_words_beam=20, engine=None):
     """W (n x k), H (k x d) >= 0.  'random' | 'smart_random' | 'nndsvd' | 'nndsvda' | 'nndsvdar'.
     engine: an RRIEngine that already holds X -- the SVD behind the NNDSVD variants then runs its products
-    with X on the device (randomized_svd_device); None = scikit-learn on the host, as the reference."""
+    with X on the device (randomized_svd_device); None = scikit-learn on the host, as the reference.
+    An engine with a row group attached (engine.group): X is this rank's row block; W comes back for these rows, H
+    replicated -- the start the one-handle call would give for the whole matrix (randomized_svd_sharded)."""
+    group = getattr(engine, 'group', None)
+    if group is not None:
+        return _initialize_nmf_sharded(X, n_components, init, eps, random_state, row_normalize, engine, group)
     n, d = X.shape
     k = n_components
     # X may be a scipy sparse matrix: randomized_svd and .mean() take it as it is
@@ -138,6 +208,42 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, row_
         fill = X.mean()
         W[W == 0] = abs(fill * rng.randn(len(W[W == 0])) / 100)
         H[H == 0] = abs(fill * rng.randn(len(H[H == 0])) / 100)
+    return W, (normalize(H) if row_normalize else H)
+
+
+def _initialize_nmf_sharded(X, k, init, eps, random_state, row_normalize, engine, group):
+    """initialize_nmf for a row block of the group's matrix: what every branch above computes, with the sums over rows
+    all-reduced and the random draws made for the WHOLE matrix on every rank (same generator, same order), so that the
+    result is the one-handle start cut into row blocks."""
+    d = engine.d
+    lo, hi, n = group.row_lo, group.row_lo + group.n_local, group.n_global
+    comm_sum = lambda A: engine.comm_sum(np.ascontiguousarray(np.asarray(A, dtype=np.float64)).ravel()).reshape(np.shape(A))
+    if init is None:
+        init = 'nndsvd' if k < d else 'random'
+    mean = lambda: float(comm_sum(np.array([engine.X_times(np.ones((d, 1))).sum()]))[0]) / (float(n) * d)
+    if init == 'random':
+        rng = check_random_state(random_state)
+        H = rng.rand(k, d)
+        W = rng.rand(n, k)[lo:hi]
+        return W, (normalize(H) if row_normalize else H)
+    if init == 'smart_random':
+        rng = check_random_state(random_state)
+        scale = np.sqrt(mean() / k)
+        H = np.abs(scale * rng.randn(k, d))
+        W = np.abs(scale * rng.randn(n, k))[lo:hi]
+        return W, (normalize(H) if row_normalize else H)
+    if init not in _KNOWN:
+        raise ValueError('Invalid init parameter: got %r instead of one of %r' % (init, _KNOWN[:1] + _KNOWN[3:]))
+    U, S, V = randomized_svd_sharded(engine, k, random_state=random_state)
+    W, H = _nndsvd_factors_vectorised(U, S, V, comm_sum)
+    W[W < eps] = 0
+    H[H < eps] = 0
+    if init == 'nndsvda':
+        fill = mean()
+        W[W == 0] = fill
+        H[H == 0] = fill
+    elif init == 'nndsvdar':
+        raise NotImplementedError("init='nndsvdar' draws one number per zero entry of the whole W: not built row-sharded")
     return W, (normalize(H) if row_normalize else H)
 
 

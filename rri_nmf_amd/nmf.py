@@ -11,8 +11,10 @@ additions select the device side:
             2e7 entries of X on.  Same algorithm either way.
     group   row-sharded run over the GPUs of one node (distributed.RowGroup): X, W_in (and W_mat) are
             THIS rank's row block, T_in is the replicated k x d factor; every rank makes the same call and gets its
-            rows of W, the common T and the global objective history.  W_in and T_in must be given.  The reference
-            has one call for the whole X (nmf.py:98-108); this is that call, made once per rank.
+            rows of W, the common T and the global objective history.  Without W_in / T_in the start is computed
+            row-sharded too (initialization.randomized_svd_sharded: the one-handle start, cut into row blocks;
+            unweighted, n_global >= d).  The reference has one call for the whole X (nmf.py:98-108); this is that
+            call, made once per rank.
     schedule  'gram' (default): the residual is never formed, X is read once per topic step; 'residual': the explicit
             residual R = X - W T is kept in HBM and updated by rank-one terms (the form north_star names; unweighted,
             both halves free, k >= 2).  Same results to rounding.
@@ -375,8 +377,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if group is not None:
         # host work that would need the other ranks' rows (the SVD behind the NNDSVD start, document frequencies,
         # per-row weights with their refit) or that decides per rank (callbacks) is not part of the sharded call
-        if _is_empty(W_in) or _is_empty(T_in):
-            raise ValueError('a row-sharded call needs W_in (this rank\'s rows) and T_in')
+        if (_is_empty(W_in) or _is_empty(T_in)) and W_mat is not None:
+            raise ValueError('a row-sharded weighted call needs W_in (this rank\'s rows) and T_in')
         if w_row is not None or preprocess is not None or store_gradients or (eps_gauss_t and delta_gauss_t) or \
                 callable(early_stop) or schedule != 'gram':
             raise NotImplementedError('w_row, preprocess, store_gradients, the Gaussian mechanism, early_stop callbacks '
@@ -448,7 +450,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         w_row_sum = w_row_sum.reshape((w_row_sum.size, 1))
         if w_row is not None:
             w_row_sum = np.sqrt(w_row_sum)
-    if n <= k:
+    if (group.n_global if group is not None else n) <= k:
         init = 'random'
 
     clock0 = time.perf_counter()
@@ -480,7 +482,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
                                         random_state=random_state, project_T_each_iter=project_T_each_iter,
                                         project_W_each_iter=project_W_each_iter, w_row_sum=w_row_sum,
                                         t_row_sum=t_row_sum, fix_W=fix_W, fix_T=fix_T, n=n, d=d,
-                                        engine=eng if (on_device and needs_init and init not in ('random', 'smart_random')) else None)
+                                        engine=eng if (group is not None or (on_device and needs_init and init not in ('random', 'smart_random'))) else None)
         eng.set_W(W)
         eng.set_T(T)
         eng.set_params(fix_W=fix_W, fix_T=fix_T, project_T_each_iter=project_T_each_iter,

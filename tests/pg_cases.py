@@ -50,6 +50,11 @@ GROUP_CASES = {
     'resets_W_random': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random', fix_reset_seed=True)),
     'weighted_resets_T': (600, 200, 4, 2, True, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
     'c4_proportions_unequal': (100003, 1000, 50, 1, False, 'float32', dict()),
+    # no W_in / T_in: the start itself is computed row-sharded (initialization.randomized_svd_sharded and friends)
+    'start_nndsvd': (1501, 700, 6, 3, False, 'float64', dict(_init='nndsvd', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'start_nndsvda_f32': (2000, 333, 8, 2, False, 'float32', dict(_init='nndsvda')),
+    'start_smart_random': (900, 333, 5, 2, False, 'float64', dict(_init='smart_random')),
+    'start_nndsvd_fold_in': (1000, 400, 5, 4, False, 'float64', dict(_init='nndsvd', _T_in=True, fix_T=True, t_row_sum=1.0, w_row_sum=1.0)),
 }
 
 
@@ -57,8 +62,16 @@ def nmf_inputs(name):
     """(X, W_mat, W0, T0, k, keyword arguments of nmf()) of a case, all rows"""
     import scipy.sparse as sp
     n, d, k, sweeps, weighted, store, flags = GROUP_CASES[name]
+    flags = dict(flags)
     X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
+    init = flags.pop('_init', None)
+    keep_T = flags.pop('_T_in', False)
     kw = dict(max_iter=sweeps, eps_stop=-1, compute_obj_each_iter=True, dtype=np.dtype(store), **flags)
+    if init is not None:       # the start comes from initialize_nmf (the fold-in case keeps T_in, as the estimators' transform does)
+        kw.update(init=init, random_state=0, device_init=True)
+        W0 = []
+        if not keep_T:
+            T0 = []
     if weighted == 'sparse':
         A = sp.csr_matrix(M)
         A.data = np.asarray(X[M > 0], dtype=np.float64)
@@ -91,9 +104,36 @@ def case_group_host_transport(out, name):
             np.random.seed(12345)         # only rank 0's generator may matter for 'random' resets
         with RowGroup.over_torch(hi - lo) as grp:
             assert (grp.row_lo, grp.n_global) == (lo, n)
-            r = nmf_mod.nmf(X[lo:hi], k, W_mat=None if M is None else M[lo:hi], W_in=W0[lo:hi], T_in=T0, group=grp, **kw)
+            r = nmf_mod.nmf(X[lo:hi], k, W_mat=None if M is None else M[lo:hi], W_in=W0[lo:hi] if len(W0) else [], T_in=T0, group=grp, **kw)
             obj2 = r['obj_calculator'].true_objective()       # collective re-evaluation on a fresh handle
         np.savez(out, W=r['W'], T=r['T'], obj=np.array(r['obj_history']), obj2=obj2, resets=r['n_resets_used'], lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+def estimator_problem():
+    from rri_nmf_amd.synthetic import planted_X
+    X = planted_X(1200, 300, 6, seed=9, dtype=np.float64)
+    return X / X.sum(1, keepdims=True)            # documents as distributions, what the topic-model estimator expects
+
+
+def case_group_estimator(out):
+    """NMF_TM_Estimator.fit on a row block with nmf_kwargs={'group': ...}: the estimator's own NNDSVD start computed
+    row-sharded, 5 sweeps, final projection; then one_iter from its factors"""
+    import torch.distributed as dist
+    from rri_nmf_amd import sklearn_interface as si
+    from rri_nmf_amd.distributed import RowGroup
+    rank, world = _init_pg('gloo')
+    try:
+        X = estimator_problem()
+        n, d = X.shape
+        lo, hi = (0, 700) if rank == 0 else (700, n)
+        with RowGroup.over_torch(hi - lo) as grp:
+            E = si.NMF_TM_Estimator(hi - lo, d, 6, random_state=0, max_iter=5,
+                                    nmf_kwargs={'group': grp, 'eps_stop': -1, 'device_init': True}).fit(X[lo:hi])
+            W5, T5 = E.W.copy(), E.T.copy()
+            E.one_iter(X[lo:hi])
+        np.savez(out, W=W5, T=T5, W6=E.W, T6=E.T, obj=np.array(E.nmf_outputs['obj_history']), lo=lo, hi=hi)
     finally:
         dist.destroy_process_group()
 

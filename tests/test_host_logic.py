@@ -373,8 +373,8 @@ def test_row_sharded_call_is_checked_before_any_device_work():
     assert (view.row_lo, view.n_local, view.n_global) == (5, 6, 18)
     view.close(), grp.close()                                     # a view never destroys the communicator; None is nothing to destroy
     assert [shard_rows(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
-    with pytest.raises(ValueError, match='W_in'):
-        nmf_mod.nmf(X, 3, group=grp)
+    with pytest.raises(ValueError, match='W_in'):          # a weighted problem has no row-sharded start
+        nmf_mod.nmf(X, 3, W_mat=np.ones_like(X), group=grp)
     for kw in (dict(w_row=np.ones((12, 1))), dict(preprocess='normalize'), dict(store_gradients=True),
                dict(eps_gauss_t=1.0, delta_gauss_t=0.1), dict(early_stop=lambda X, W, T: 0.0), dict(schedule='residual')):
         with pytest.raises(NotImplementedError):

@@ -397,6 +397,8 @@ struct TimedScope {
 int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8).  nt: -1 = per handle (non-temporal
                                                         // loads where X cannot stay in the caches, plain loads where it can)
 int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
+int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted pass with a bit-packed mask: 8 (one mask word per
+                         // chunk; +1.3 % at C5 over 4, 16 falls to one wave per SIMD: profiles/r02_weighted_pass_variants.log) or 4
 int g_sp_merge = 1;      // RRI_SP_MERGE=0: pattern-only handles run the dense flavour's schedule (row copy: read pass + write pass)
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
@@ -519,12 +521,13 @@ struct LaunchX {
                       const double* a2, const double* b2) {
         TimedScope ts(c, 3);
         if (c->sparse) { sp_wpass<DO_Y, DO_Z, UPD2, WRITE>(c, trow, wc, a1, b1, a2, b2); return; }
-        // rows in flight: 8 for the passes that take row products (they use the LDS row sums), 4 for the
-        // writing pass (two rank-one corrections and two sets of accumulators: 4 rows keep it at 4 waves/SIMD)
+        // rows in flight: 8 for the passes that take row products (they use the LDS row sums); the writing pass (two
+        // rank-one corrections, two sets of accumulators): 4 with an fp mask array, 8 with a bit-packed mask
         constexpr int U = DO_Y ? 8 : 4;
         const bool rs = DO_Y && g_pass_rs;
         if (c->Mbits) {
             if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
+            else if (!DO_Y && g_wpass_uc == 8) wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, 8, false>(c, trow, wc, a1, b1, a2, b2);
             else wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, U, false>(c, trow, wc, a1, b1, a2, b2);
         } else {
             if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
@@ -1463,6 +1466,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_FUSE_W")) g_fuse_w = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_IL")) g_wpass_il = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_SP_MERGE")) g_sp_merge = atoi(e) != 0;
+    if (const char* e = getenv("RRI_WPASS_UC")) g_wpass_uc = atoi(e) == 4 ? 4 : 8;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
 #define CR(call)                                                                                   \

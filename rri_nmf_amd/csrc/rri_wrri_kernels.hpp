@@ -174,10 +174,13 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
             // load per chunk.  (Loaded row by row, as the array form below must be, the same word was requested U times:
             // as many vector-memory instructions again as the residual itself takes, PMC SQ_INSTS_VMEM_RD 8.1e6 against
             // 4.1e6 for k_pass on the same bytes -- profiles/r02_pmc_sq_c5_before_mask_word_fix.txt.)
-            unsigned mword = 0u;
+            constexpr int NW = (U + 7) / 8;          // mask words per chunk: 8 rows each
+            unsigned mword[NW];
             if constexpr (MBITS) {
-                static_assert(U == 4 || U == 8, "a chunk of rows must lie inside one 8-row mask word");
-                if (ok) mword = Mb[(i64)(r >> 3) * ldb + (col >> 2)] >> (col & 3);
+                static_assert(U == 4 || U % 8 == 0, "a chunk of rows must be whole 8-row mask words (or half of one)");
+#pragma unroll
+                for (int q = 0; q < NW; ++q)
+                    mword[q] = (ok && r + 8 * q < row1) ? Mb[(i64)((r >> 3) + q) * ldb + (col >> 2)] >> (col & 3) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 mk[u] = MaskLoad<SX, MBITS>::zero();
                 if (rr < row1 && ok) {
                     x[u] = stream_load<NT>(reinterpret_cast<const V*>(E + (i64)rr * ldx + col));
-                    if constexpr (MBITS) mk[u] = mword >> ((rr & 7) << 2);
+                    if constexpr (MBITS) mk[u] = mword[u >> 3] >> ((rr & 7) << 2);
                     else mk[u] = MaskLoad<SX, MBITS>::load(M, ldm, Mb, ldb, rr, col);
                 }
             }

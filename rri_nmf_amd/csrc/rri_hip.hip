@@ -670,7 +670,17 @@ struct LaunchX {
         if (c->k <= 64 && g_resid_mfma) {   // the k-panel product on the matrix cores
             const int ks = c->k <= 16 ? 4 : c->k <= 32 ? 8 : c->k <= 48 ? 12 : c->k <= 52 ? 13 : 16;
             const size_t shm = 2 * (size_t)(4 * ks) * 64 * sizeof(double);
-#define RRI_RESID_M(MK, WE, KS_)                                                                                     \
+            const bool sums = rowobj || rowpos;      // a plain rebuild wants neither: its epilogue is convert, subtract, store
+#define RRI_RESID_M2(MK, WE, KS_, SM)                                                                                \
+    hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4, SM>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
+                       (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,      \
+                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+#define RRI_RESID_M(MK, WE, KS_)                           \
+    do {                                                   \
+        if (WE && !sums) RRI_RESID_M2(MK, WE, KS_, false); \
+        else RRI_RESID_M2(MK, WE, KS_, true);              \
+    } while (0)
+#define RRI_RESID_M_UNUSED(MK, WE, KS_)                                                                              \
     hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
                        (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,      \
                        (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
@@ -688,6 +698,8 @@ struct LaunchX {
             else RRI_RESID_K(false, false)
 #undef RRI_RESID_K
 #undef RRI_RESID_M
+#undef RRI_RESID_M2
+#undef RRI_RESID_M_UNUSED
             return;
         }
         const size_t sh = resid_shmem(c);

@@ -1326,7 +1326,8 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
 // =========================================================================================
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <typename SX, bool MASKED, bool WRITE_E, int KS, int WAVES>   // KS = k-steps of 4 (4, 8, 12, 13 or 16): k <= 4 KS
+// SUMS = false (a rebuild of the stored residual that wants neither row sums): the epilogue is convert, subtract, store.
+template <typename SX, bool MASKED, bool WRITE_E, int KS, int WAVES, bool SUMS = true>   // KS = k-steps of 4 (4, 8, 12, 13 or 16): k <= 4 KS
 __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M,
                                                     i64 ldm, const unsigned* __restrict__ Mb, i64 ldb,
                                                     const double* __restrict__ Wt, i64 ldw,
@@ -1352,6 +1353,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
     double stage[NST];
     typedef typename std::conditional<sizeof(SX) == 4, float, double>::type XR;
     XR xq[4][4];                                     // the lane's 4 rows x 4 consecutive columns of X, as stored
+    XR xn[4][4];                                     // ... of the NEXT step: requested at the start of a step, so that
+                                                     // nothing issued late in a step is waited for before its barrier
     auto fetch = [&](i64 c0) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
@@ -1366,7 +1369,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
     };
     // X: rows row0 + lk + 4r, columns c0 + 4 lr .. + 3 (a 16-byte vector when the storage type is fp32 and the
     // columns are all there; elementwise at the ragged edge and for fp64 storage)
-    auto fetch_x = [&](i64 c0) {
+    auto fetch_x = [&](i64 c0, XR (&dst)[4][4]) {
         const i64 j = c0 + 4 * lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1375,25 +1378,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
             if constexpr (sizeof(SX) == 4) {
                 if (i < n && j + 3 < d) {
                     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + i * ldx + j));
-                    xq[r][0] = v[0]; xq[r][1] = v[1]; xq[r][2] = v[2]; xq[r][3] = v[3];
+                    dst[r][0] = v[0]; dst[r][1] = v[1]; dst[r][2] = v[2]; dst[r][3] = v[3];
                     done = true;
                 }
             }
             if (!done) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xq[r][c] = (i < n && j + c < d) ? (XR)X[i * ldx + j + c] : XR(0);
+                for (int c = 0; c < 4; ++c) dst[r][c] = (i < n && j + c < d) ? (XR)X[i * ldx + j + c] : XR(0);
             }
         }
     };
     double so[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
     fetch(0);
-    fetch_x(0);
+    fetch_x(0, xq);
     park(0);
     __syncthreads();
     int buf = 0;
     for (i64 c0 = 0; c0 < d; c0 += 64, buf ^= 1) {
         const bool more = c0 + 64 < d;
-        if (more) fetch(c0 + 64);                    // the next T tile: in flight during the MFMAs below
+        if (more) {                                  // the next T tile AND the next X tile: in flight during the MFMAs
+            fetch(c0 + 64);                          // and the epilogue below (round 1 asked for X after the epilogue and
+            fetch_x(c0 + 64, xn);                    // then waited for it -- vmcnt(0) before the park -- once per step)
+        }
         f64x4 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -1422,11 +1428,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
                 if (j < d) {
                     e = (double)xq[r][c] - acc[c][r];
                     m = !MASKED ? 1.0 : (Mb ? (double)((bits >> c) & 1u) : (double)M[i * ldm + j]);
-                    so[r] += m * e * e;
-                    const double ep = e > 0.0 ? e : 0.0;
-                    sp[r] += ep * ep;
+                    if constexpr (SUMS) {
+                        so[r] += m * e * e;
+                        const double ep = e > 0.0 ? e : 0.0;
+                        sp[r] += ep * ep;
+                    }
                 }
-                ev[c] = m * e;
+                ev[c] = MASKED ? m * e : e;
             }
             if (WRITE_E) {
                 bool stored = false;
@@ -1445,11 +1453,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
             }
         }
         if (more) {
-            fetch_x(c0 + 64);                        // the next X tile: in flight during the next step's MFMAs
             park(buf ^ 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xq[r][c] = xn[r][c];
         }
         __syncthreads();
     }
+    if constexpr (!SUMS) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll

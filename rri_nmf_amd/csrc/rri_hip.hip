@@ -675,15 +675,13 @@ struct LaunchX {
     hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4, SM>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
                        (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,      \
                        (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+// a residual written without its row sums (the per-sweep rebuild of the explicit-residual schedule) skips them; !(WE)
+// keeps the first branch from instantiating a kernel that no WRITE_E = false caller can reach
 #define RRI_RESID_M(MK, WE, KS_)                           \
     do {                                                   \
-        if (WE && !sums) RRI_RESID_M2(MK, WE, KS_, false); \
+        if (WE && !sums) RRI_RESID_M2(MK, WE, KS_, !(WE)); \
         else RRI_RESID_M2(MK, WE, KS_, true);              \
     } while (0)
-#define RRI_RESID_M_UNUSED(MK, WE, KS_)                                                                              \
-    hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
-                       (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,      \
-                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
 #define RRI_RESID_K(MK, WE)                          \
     switch (ks) {                                    \
         case 4: RRI_RESID_M(MK, WE, 4); break;       \
@@ -699,7 +697,6 @@ struct LaunchX {
 #undef RRI_RESID_K
 #undef RRI_RESID_M
 #undef RRI_RESID_M2
-#undef RRI_RESID_M_UNUSED
             return;
         }
         const size_t sh = resid_shmem(c);

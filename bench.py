@@ -75,6 +75,7 @@ def parse():
     ap.add_argument('--collective', default='library', choices=['library', 'torch'],
                     help='row-sharded runs: library = RCCL inside librri_hip.so, the all-reduce enqueued by rri_sweep itself '
                          '(default); torch = the caller-owned protocol, torch.distributed per topic step from Python')
+    ap.add_argument('--comm-probe', default='', help=argparse.SUPPRESS)    # child mode of probe_library_collective()
     return ap.parse_args()
 
 
@@ -91,6 +92,71 @@ def relaunch_under_torchrun(args):
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+PROBE_SECONDS = 240
+
+
+def comm_probe_child(ident_hex):
+    """Child mode (`--comm-probe <RCCL id of rank 0>`): this rank's share of ONE in-library all-reduce among the ranks of
+    the job -- communicator created by rri_comm_create, a tiny handle attached, sum of (rank + 1) checked -- in a
+    process of its own that gives up (stack trace, exit 1) instead of stalling."""
+    import faulthandler
+    faulthandler.dump_traceback_later(PROBE_SECONDS - 30, exit=True)
+    import numpy as np
+    from rri_nmf_amd.distributed import RowGroup
+    from rri_nmf_amd.engine import RRIEngine
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dev = int(os.environ.get('RRI_PROBE_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    ident = bytes.fromhex(ident_hex)
+    grp = RowGroup.rccl(64, device=dev, exchange=lambda obj: [(ident, 64)] * world, rank=rank, world=world)
+    eng = RRIEngine(64, 32, 2, device=dev)
+    eng.attach_group(grp)
+    got = eng.comm_sum(np.array([rank + 1.0, 1.0]))
+    want = [world * (world + 1) / 2.0, float(world)]
+    eng.close()
+    grp.close()
+    if list(got) != want:
+        print('comm probe: sum %r, expected %r' % (list(got), want))
+        return 1
+    print('comm probe ok')
+    return 0
+
+
+def probe_library_collective(rank, world, device_index):
+    """Before this process creates the in-library RCCL communicator it lets a child per rank do exactly that once
+    (comm_probe_child).  A bootstrap that cannot complete on this box then costs a bounded wait and the run falls
+    back to torch.distributed's communicator, saying so in the line, instead of stalling every rank inside
+    ncclCommInitRank where nothing can interrupt it.  Returns (usable on every rank, reason)."""
+    import ctypes as C
+    import torch.distributed as dist
+    from rri_nmf_amd import _capi
+    lib = _capi.load_library()
+    _capi.share_rccl_with_torch()
+    ident = ''
+    if rank == 0:
+        buf = (C.c_uint8 * _capi.RRI_COMM_ID_BYTES)()
+        if lib.rri_comm_unique_id(buf) == _capi.RRI_OK:
+            ident = bytes(bytearray(buf)).hex()
+    got = [None] * world
+    dist.all_gather_object(got, ident)
+    ident = got[0]
+    ok, why = False, 'rri_comm_unique_id failed'
+    if ident:
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), RRI_PROBE_DEVICE=str(device_index))
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--comm-probe', ident], env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            log, _ = child.communicate(timeout=PROBE_SECONDS)
+            ok = child.returncode == 0 and 'comm probe ok' in log
+            why = '' if ok else 'rank %d: exit %s: %s' % (rank, child.returncode, log[-300:].replace('\n', ' | '))
+        except subprocess.TimeoutExpired:
+            child.kill()                     # the exact PID started above
+            child.communicate()
+            why = 'rank %d: no answer in %d s' % (rank, PROBE_SECONDS)
+    verdicts = [None] * world
+    dist.all_gather_object(verdicts, (ok, why))
+    return all(v[0] for v in verdicts), '; '.join(v[1] for v in verdicts if v[1])
 
 
 def source_stamp():
@@ -154,11 +220,18 @@ def cpu_plain(X_dev, W0, T0, rows, sweeps, threads, n_full, want_factors=True):
 
 def main():
     args = parse()
+    if args.comm_probe:
+        sys.exit(comm_probe_child(args.comm_probe))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world == 1:
         sys.exit(relaunch_under_torchrun(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on stdout when a communicator
+    # comes up, so whatever the libraries write to descriptor 1 during the run goes to stderr instead
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     # Rehearsal of the multi-rank path on a ONE-GPU box (never the measured configuration): RRI_BENCH_REHEARSAL=1 puts
     # every rank on device 0 and runs the collectives over gloo (RCCL wants one device per rank)
     rehearsal = os.environ.get('RRI_BENCH_REHEARSAL', '0') == '1'
@@ -181,6 +254,8 @@ def main():
     if args.schedule == 'residual' and (sharded or weighted):
         sys.exit('--schedule residual is the unweighted flavour on one GPU')
     if sharded:
+        import faulthandler
+        faulthandler.dump_traceback_later(600, repeat=True)     # a rank that waits for its peers says where, every 10 min
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if 'MASTER_PORT' not in os.environ:
             os.environ['MASTER_PORT'] = str(free_port())
@@ -228,6 +303,9 @@ def main():
     flavour = 'sparse' if sparse else weighted
     if sharded and args.collective == 'library' and not rehearsal:
         try:
+            usable, why = probe_library_collective(rank, world, local_rank)
+            if not usable:
+                raise RuntimeError('probe: ' + why)
             group = RowGroup.rccl(n_local, device=local_rank)
             collective = 'RCCL inside librri_hip.so: one ncclAllReduce per topic step enqueued by rri_sweep on the handle\'s stream'
         except Exception as e:  # noqa: BLE001  (measurement robustness: say so in the line and use the caller-owned protocol)
@@ -606,7 +684,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + '\n').encode())
+    os.close(line_fd)
 
 
 if __name__ == '__main__':

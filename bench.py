@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--schedule', default='gram', choices=['gram', 'residual'],
                     help="gram: X is read once per topic step (default); residual: the explicit residual R = X - WT is "
-                         "updated by rank-one terms, one read-modify-write pass per topic step (unweighted, one GPU)")
+                         "updated by rank-one terms, one read-modify-write pass per topic step (unweighted)")
     ap.add_argument('--cpu-sweeps', type=int, default=2)
     ap.add_argument('--cpu-rows', type=int, default=0,
                     help='rows of X in the CPU baseline (0 = the workload default: all rows for c2 / c3, 100000 for c4)')
@@ -251,8 +251,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     sharded = world > 1 or args.force_sharded
-    if args.schedule == 'residual' and (sharded or weighted):
-        sys.exit('--schedule residual is the unweighted flavour on one GPU')
+    if args.schedule == 'residual' and (weighted or (sharded and args.collective != 'library')):
+        sys.exit('--schedule residual is the unweighted flavour; row-sharded it needs the in-library collective')
     if sharded:
         import faulthandler
         faulthandler.dump_traceback_later(600, repeat=True)     # a rank that waits for its peers says where, every 10 min
@@ -319,9 +319,16 @@ def main():
             if collective == 'none':
                 collective = 'torch.distributed all_reduce per topic step from Python (caller-owned protocol)'
     if group is not None:
-        eng = RRIEngine(n_local, d, k, dtype=sdt, weighted=flavour, device=local_rank)
+        eng = RRIEngine(n_local, d, k, dtype=sdt, weighted=flavour, device=local_rank, schedule=args.schedule)
         eng.attach_group(group)
+        # one all-reduce of the size a topic step sends, checked: the ranks really are connected, and the connections of
+        # that message size exist before the timed region whatever --warmup is
+        ones = eng.comm_sum(np.ones((2 * d + 2) if weighted else (d + 8 * (k + 2))))
+        if not np.all(ones == float(world)):
+            raise SystemExit('in-library all-reduce returned %r on rank %d, expected %d everywhere' % (ones[:4], rank, world))
     elif sharded:
+        if args.schedule == 'residual':
+            sys.exit('--schedule residual row-sharded needs the in-library collective: ' + collective)
         eng, red, stream = make_device_shard(n_local, d, k, dtype=sdt, device_index=local_rank, weighted=flavour)
     else:
         eng = RRIEngine(n_local, d, k, dtype=sdt, weighted=flavour, device=local_rank, schedule=args.schedule)

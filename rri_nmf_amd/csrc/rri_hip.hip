@@ -1109,7 +1109,7 @@ void enqueue_rT_half(rri_ctx* c, int sweep, int t, bool standalone) {
     if (!c->resid_valid) r_refresh(c);
     if (!c->carry_valid || c->carry_topic != t) {
         if (c->pending_wcheck) {            // reads Gpart, which the prologue overwrites
-            LK::check_wcol(c, c->pending_wcheck_topic, sweep, t);
+            wcheck_now(c, c->pending_wcheck_topic, sweep, t);
             c->pending_wcheck = false;
         }
         if (c->dw_pending) r_refresh(c);    // no pass to fold the pending column change into: rebuild instead
@@ -1121,10 +1121,13 @@ void enqueue_rT_half(rri_ctx* c, int sweep, int t, bool standalone) {
     {
         TimedScope ts(c, 2);
         const int chk = c->pending_wcheck ? 1 : 0;
-        if (LK::small(c)) {
+        if (LK::small(c) && !c->comm) {
             LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
         } else {
+            // row-sharded: every rank holds its rows of R; the column sums R^T w_t, <dw, w_t>, ||w_t||^2 and the column
+            // sum of the last update are sums over rows, all-reduced in one message as in the Gram form
             LK::reduce(c);
+            comm_allreduce(c, c->red, c->LD + (i64)GRAM_SLICES * (c->k + 2));
             LK::trow(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
         }
         c->pending_wcheck = false;
@@ -2829,7 +2832,6 @@ rri_status rri_attach_comm(rri_ctx* c, rri_comm* comm, int64_t row_offset, int64
         invalidate(c);
         return RRI_OK;
     }
-    if (c->explicit_resid) return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded runs use the Gram-form schedule");
     if (row_offset < 0 || n_global < row_offset + c->n) return fail(c, RRI_ERR_INVALID, "row block [%lld, %lld) outside 0..%lld", (long long)row_offset, (long long)(row_offset + c->n), (long long)n_global);
     if (comm->nccl && comm->device != c->device) return fail(c, RRI_ERR_INVALID, "communicator lives on device %d, handle on %d", comm->device, c->device);
     HIPCHK(c, hipSetDevice(c->device));

@@ -380,9 +380,9 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         if (_is_empty(W_in) or _is_empty(T_in)) and W_mat is not None:
             raise ValueError('a row-sharded weighted call needs W_in (this rank\'s rows) and T_in')
         if w_row is not None or preprocess is not None or store_gradients or (eps_gauss_t and delta_gauss_t) or \
-                callable(early_stop) or schedule != 'gram':
-            raise NotImplementedError('w_row, preprocess, store_gradients, the Gaussian mechanism, early_stop callbacks '
-                                      'and schedule=\'residual\' are single-handle options')
+                callable(early_stop):
+            raise NotImplementedError('w_row, preprocess, store_gradients, the Gaussian mechanism and early_stop callbacks '
+                                      'are single-handle options')
     draw_noise = None
     if eps_gauss_t and delta_gauss_t and not fix_T:
         # Gaussian mechanism on the T-row sums (nmf.py:422-435; Dwork & Roth p. 261)

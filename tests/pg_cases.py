@@ -49,6 +49,10 @@ GROUP_CASES = {
     'resets_T_max_resid': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
     'resets_W_random': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random', fix_reset_seed=True)),
     'weighted_resets_T': (600, 200, 4, 2, True, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
+    # the explicit-residual schedule row-sharded: every rank keeps its rows of R, the reference is the same schedule on one handle
+    'residual_schedule_f64': (1501, 700, 6, 3, False, 'float64', dict(schedule='residual')),
+    'residual_schedule_f32_tm': (2600, 1200, 7, 3, False, 'float32', dict(schedule='residual', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'residual_schedule_resets_W': (600, 200, 4, 2, False, 'float64', dict(schedule='residual', t_row_sum=1.0, reg_w_l1=1e6)),
     'c4_proportions_unequal': (100003, 1000, 50, 1, False, 'float32', dict()),
     # no W_in / T_in: the start itself is computed row-sharded (initialization.randomized_svd_sharded and friends)
     'start_nndsvd': (1501, 700, 6, 3, False, 'float64', dict(_init='nndsvd', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),

@@ -104,6 +104,10 @@ def test_two_ranks_through_nmf_equal_one_handle(name, tmp_path, cases):
     # float64 storage: the order of the row sums only.  fp32 residual of the weighted flavour: the one-handle run
     # below a launch-bound size fuses its small reductions differently and the stored residual rounds apart: 1e-4
     tol = 1e-4 if (store == 'float32' and weighted) else 1e-9
+    if name.startswith('residual_schedule') and store == 'float32':
+        # the stored residual is fp32: a row sum that differs in its last float64 bit between two shards and one handle can
+        # move a stored entry by one fp32 ulp
+        tol = 1e-6
     if name.startswith('start_'):
         # the start itself is computed row-sharded: the tall factorisations of the randomized SVD go through Cholesky-QR
         # on an all-reduced Gram matrix instead of one LU / QR -- another basis of the same range, the same U, S, V to

@@ -376,7 +376,7 @@ def test_row_sharded_call_is_checked_before_any_device_work():
     with pytest.raises(ValueError, match='W_in'):          # a weighted problem has no row-sharded start
         nmf_mod.nmf(X, 3, W_mat=np.ones_like(X), group=grp)
     for kw in (dict(w_row=np.ones((12, 1))), dict(preprocess='normalize'), dict(store_gradients=True),
-               dict(eps_gauss_t=1.0, delta_gauss_t=0.1), dict(early_stop=lambda X, W, T: 0.0), dict(schedule='residual')):
+               dict(eps_gauss_t=1.0, delta_gauss_t=0.1), dict(early_stop=lambda X, W, T: 0.0)):
         with pytest.raises(NotImplementedError):
             nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, group=grp, **kw)
     with pytest.raises(NotImplementedError):

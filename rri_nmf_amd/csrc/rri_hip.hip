@@ -31,6 +31,7 @@
 #include "rri_kernels.hpp"
 #include "rri_wrri_kernels.hpp"
 #include "rri_sparse_kernels.hpp"
+#include "rri_onchip_kernels.hpp"
 
 using namespace rri;
 
@@ -234,6 +235,12 @@ struct rri_ctx {
     double* cand = nullptr;    // 2 * world doubles (device): candidates of the max-residual reset
     rri_status comm_status = RRI_OK;   // first failure of a collective inside an enqueued sequence
 
+    // register-resident sweeps (rri_onchip_kernels.hpp): per-workgroup partial arrays and the grid barrier's counter
+    int n_cu = 0;
+    double *mkZ = nullptr, *mkG = nullptr, *mkP = nullptr;
+    unsigned* mkbar = nullptr;
+    long onchip_launches = 0;
+
     int timing = 0;            // 0 off, N > 0: time every N-th launch of each kernel id
     long timing_seq[4] = {0, 0, 0, 0};
     std::vector<TimedLaunch> timed[4];
@@ -402,6 +409,7 @@ int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted
 int g_sp_merge = 1;      // RRI_SP_MERGE=0: pattern-only handles run the dense flavour's schedule (row copy: read pass + write pass)
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
+int g_onchip = 1;       // RRI_ONCHIP=0: never the register-resident persistent sweep (rri_onchip_kernels.hpp)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
 int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
                         // launch-bound sizes, 2 always
@@ -1345,6 +1353,130 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) 
     }
 }
 
+// ---- register-resident persistent sweeps (rri_onchip_kernels.hpp) ---------------------------------------------
+struct OnchipGeom { int CG, RG, rows_wg, rpw, NA, kS, G; size_t shmem; };
+constexpr int ONCHIP_MAX_K = 22;      // k + 2 Gram entries = 8 waves x 3 in flight: one round trip in phase A.  Beyond that the
+                                      // per-topic cost of the kernel grows faster than that of the launch-per-phase schedule
+                                      // (5000 x 1000: -3 % at k = 24 and 32, -15 % at k = 64; profiles/r02_onchip_sizes.log)
+constexpr int ONCHIP_MAX_RPW = 20;    // rows per wave held in registers (float4 each): 32 spills at 256 VGPRs
+bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
+    if (c->LD > 1024 || c->n_cu < 1) return false;
+    g->G = c->n_cu;
+    g->CG = c->LD <= 256 ? 1 : c->LD <= 512 ? 2 : 4;
+    g->RG = ONCHIP_WAVES / g->CG;
+    g->rows_wg = (int)((c->n + g->G - 1) / g->G);
+    g->rpw = (g->rows_wg + g->RG - 1) / g->RG;
+    g->NA = (int)((c->LD + ONCHIP_CWA - 1) / ONCHIP_CWA);      // workgroups that also own a column slice of T
+    g->kS = c->k | 1;                                  // odd row stride of the LDS copy of W: no bank conflicts down a column
+    if (g->rpw > ONCHIP_MAX_RPW || g->NA > 64 || g->NA > g->G || (i64)g->rows_wg * g->kS > 6144) return false;
+    const size_t doubles = (size_t)g->rows_wg * g->kS + (size_t)c->k * ONCHIP_CWA + (c->k + 2) + (c->k + 1) +
+                           (size_t)ONCHIP_PG * ONCHIP_CWA + (size_t)g->CG * g->rows_wg + g->rows_wg +
+                           (size_t)ONCHIP_WAVES * 256 + (size_t)ONCHIP_WAVES * 8 * 72;
+    g->shmem = doubles * sizeof(double);
+    return g->shmem <= 150 * 1024;
+}
+// what the persistent kernel covers: the plain flavour with fp32 storage, both halves free, no per-iteration projection
+// of T (the "light" configuration), k >= 2, on one device
+bool onchip_ok(const rri_ctx* c) {
+    OnchipGeom g;
+    return g_onchip && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->dtype == RRI_F32 && c->k >= 2 &&
+           c->k <= ONCHIP_MAX_K && LK::light(c) && !c->prm.fix_W && !c->prm.fix_T && c->ldx % 4 == 0 && ((uintptr_t)c->X) % 16 == 0 &&
+           onchip_geometry(c, &g);
+}
+template <int RPW, bool DBG = false>
+hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
+    static bool attr_set[64] = {};
+    const int dv = c->device & 63;
+    if (!attr_set[dv]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_onchip_sweeps<RPW, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess) { if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: hipFuncSetAttribute\n"); return e; }
+        attr_set[dv] = true;
+    }
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onchip_sweeps<RPW, DBG>, ONCHIP_THREADS, g.shmem);
+    if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: occupancy %d per CU (%s), %d CUs\n", per_cu, hipGetErrorString(e), c->n_cu);
+    if (e != hipSuccess) return e;
+    if ((i64)per_cu * c->n_cu < g.G) return hipErrorCooperativeLaunchTooLarge;     // the hand-overs need every workgroup resident
+    // a cooperative launch: the runtime keeps two such grids (two handles, two streams) from each holding a part of the
+    // device while waiting for the rest
+    OnchipArgs args = a;
+    void* argv[] = {(void*)&args};
+    return hipLaunchCooperativeKernel((const void*)k_onchip_sweeps<RPW, DBG>, dim3(g.G), dim3(ONCHIP_THREADS), argv,
+                                      (unsigned)g.shmem, c->stream);
+}
+// sweeps [cur .. run_total) in one launch; false: not launched (the caller takes the launch-per-phase schedule)
+bool enqueue_onchip(rri_ctx* c, Cursor cur) {
+    OnchipGeom g;
+    if (!onchip_geometry(c, &g)) return false;
+    const int k = c->k;
+    if (!c->mkZ) {
+        if (hipMalloc((void**)&c->mkZ, (size_t)g.G * c->LD * 8) != hipSuccess) { c->mkZ = nullptr; return false; }
+        if (hipMalloc((void**)&c->mkG, (size_t)g.G * (k + 2) * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->mkP, (size_t)64 * (k + 1) * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->mkbar, (size_t)(128 + g.G) * sizeof(unsigned)) != hipSuccess) return false;
+        (void)hipMemsetAsync(c->mkZ, 0, (size_t)g.G * c->LD * 8, c->stream);
+        (void)hipMemsetAsync(c->mkG, 0, (size_t)g.G * (k + 2) * 8, c->stream);
+        (void)hipMemsetAsync(c->mkP, 0, (size_t)64 * (k + 1) * 8, c->stream);
+    }
+    if (!c->mkG || !c->mkP || !c->mkbar) return false;
+    (void)hipMemsetAsync(c->mkbar, 0, (size_t)(128 + g.G) * sizeof(unsigned), c->stream);
+    OnchipArgs a{};
+    a.X = (const float*)c->X; a.ldx = c->ldx; a.n = (int)c->n; a.d = (int)c->d; a.LD = (int)c->LD; a.k = k;
+    a.Wt = c->W; a.ldw = c->ldw; a.T = c->T; a.ldt = c->LD;
+    a.mkZ = c->mkZ; a.mkG = c->mkG; a.mkP = c->mkP; a.xyp = c->XYpart; a.xy_stride = c->xy_stride; a.bar = c->mkbar;
+    a.G = g.G; a.NA = g.NA; a.rows_wg = g.rows_wg; a.CG = g.CG; a.RG = g.RG; a.kS = g.kS;
+    a.s0 = cur.sweep; a.t0 = cur.topic; a.ph0 = cur.phase; a.s_end = c->run_total;
+    a.skip_row_finish = c->skip_row_finish ? 1 : 0;
+    a.spin_limit = 2000000u;            // polls of ~1 us: a grid that stands still for seconds gives up (HALT_ERR_GRID_SYNC)
+    a.p = kparams(c); a.st = c->st;
+    a.dbg = nullptr;
+    if (getenv("RRI_ONCHIP_TIMING")) {           // diagnostics: per-section ticks of the last launch, printed at the next one
+        static long long* dbg = nullptr;
+        if (!dbg && hipMalloc((void**)&dbg, 32 * sizeof(long long)) != hipSuccess) dbg = nullptr;
+        if (dbg) {
+            long long h[32];
+            if (c->onchip_launches > 0 && hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+                static const char* names[8] = {"A loads", "A rest+signal", "wait workers", "B loads", "row dots", "W update", "carry", "hand-over"};
+                for (int w = 0; w < 2; ++w) {
+                    fprintf(stderr, "rri on-chip sections, workgroup %s (us total):", w == 0 ? "0 (worker)" : "G-1");
+                    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f;", names[i], h[16 * w + i] * 0.01);
+                    fprintf(stderr, "\n");
+                }
+            }
+            (void)hipMemsetAsync(dbg, 0, 32 * sizeof(long long), c->stream);
+            a.dbg = dbg;
+        }
+    }
+    hipError_t e;
+    {
+        TimedLaunch tl{nullptr, nullptr};
+        const bool timed = c->timing > 0 && c->timed[0].size() < 400000;
+        if (timed) { tl.a = get_event(c); tl.b = get_event(c); (void)hipEventRecord(tl.a, c->stream); }
+        if (a.dbg) e = g.rpw <= 8 ? onchip_launch<8, true>(c, g, a) : onchip_launch<ONCHIP_MAX_RPW, true>(c, g, a);
+        else if (g.rpw <= 8) e = onchip_launch<8>(c, g, a);
+        else e = onchip_launch<ONCHIP_MAX_RPW>(c, g, a);
+        if (timed) { (void)hipEventRecord(tl.b, c->stream); c->timed[0].push_back(tl); }
+    }
+    if (e != hipSuccess) {
+        if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: on-chip sweep not launched (%s): rows/wg %d, rows/wave %d, LDS %zu B\n", hipGetErrorString(e), g.rows_wg, g.rpw, g.shmem);
+        (void)hipGetLastError();
+        return false;
+    }
+    c->onchip_launches += 1;
+    // what the launch-per-phase schedule would find after these sweeps: no carried sums, nothing pending (the kernel
+    // ran the last column check itself); the objective's cross terms are complete when the last sweep ran from topic 0
+    const bool whole_last = c->run_total - 1 > cur.sweep || (cur.topic == 0 && cur.phase == 0);
+    c->carry_valid = false; c->carry_topic = -1;
+    c->pending_wcheck = false;
+    c->resid_valid = false; c->q_valid = false;
+    c->ttpart_topic = -1;
+    c->skip_row_finish = false;
+    c->xy_run = whole_last ? k : -1;
+    c->xy_rows = g.G;
+    c->xy_valid = whole_last;
+    return true;
+}
+
 void enqueue_final_check(rri_ctx* c, int sweep_arg) {
     if (c->pending_wcheck) {  // last column of the call: report it in this call
         wcheck_now(c, c->pending_wcheck_topic, sweep_arg, 0);
@@ -1353,6 +1485,7 @@ void enqueue_final_check(rri_ctx* c, int sweep_arg) {
 }
 
 void enqueue_from(rri_ctx* c, Cursor cur) {
+    if (cur.sweep < c->run_total && onchip_ok(c) && enqueue_onchip(c, cur)) return;
     enqueue_range(c, cur, c->run_total);
     enqueue_final_check(c, c->run_total);
 }
@@ -1417,6 +1550,8 @@ rri_status status_from_halt(rri_ctx* c, const DevState& s, int32_t* sweeps_done)
             return fail(c, RRI_ERR_W_COL_ZERO, "W[:, t] sums to 0 (topic %d)", s.halt_topic);
         case HALT_ERR_NOT_IMPLEMENTED:
             return fail(c, RRI_ERR_NOT_IMPLEMENTED, "s=%g is not yet implemented", c->prm.t_row_sum);
+        case HALT_ERR_GRID_SYNC:
+            return fail(c, RRI_ERR_HIP, "the persistent sweep's workgroups could not synchronise (not all resident); RRI_ONCHIP=0 selects the launch-per-phase schedule");
         default:
             return fail(c, RRI_ERR_INVALID, "unknown device status %d", s.halt);
     }
@@ -1466,6 +1601,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     c->kp = (int)round_up(k, 8);
     c->es = dtype == RRI_F32 ? 4 : 8;
     c->VN = (int)(16 / c->es);
+    // the switches are per process and read again by every rri_create: an unset variable means the default, not "what
+    // the last handle was created with"
+    g_pass_unroll = 8; g_pass_unroll_upd = 16; g_pass_nt = -1; g_pass_rs = 1; g_obj_direct = 0; g_pass_interleave = -1;
+    g_trow_small = 1; g_graph = 0; g_resid_mfma = 1; g_side_jobs = 1; g_fuse_w = 0; g_onchip = 1; g_wpass_il = -1;
+    g_sp_merge = 1; g_wpass_uc = 8;
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
@@ -1476,6 +1616,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     if (const char* e = getenv("RRI_FUSE_W")) g_fuse_w = atoi(e) != 0;
+    if (const char* e = getenv("RRI_ONCHIP")) g_onchip = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_IL")) g_wpass_il = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_SP_MERGE")) g_sp_merge = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_UC")) g_wpass_uc = atoi(e) == 4 ? 4 : 8;
@@ -1491,6 +1632,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         }                                                                                          \
     } while (0)
     CR(hipSetDevice(device));
+    CR(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
     if (stream) c->stream = (hipStream_t)stream;
     else { CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 
@@ -1561,7 +1703,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     CR(hipMemsetAsync(c->Zpart, 0, (size_t)c->nrb * c->LD * f8, c->stream));
     const size_t grows = (size_t)std::max(c->nwb, c->nrb);      // k_wcol leaves a row per 64-row tile, the fused pass one per row block
     c->gpart_n = c->nwb;
-    c->xy_stride = (int)std::max<size_t>(grows, (size_t)c->nwb * WCOL_TILES);
+    c->xy_stride = (int)std::max<size_t>(std::max<size_t>(grows, (size_t)c->nwb * WCOL_TILES), (size_t)std::max(c->n_cu, 1));   // the on-chip sweep leaves one per CU
     CR(hipMalloc((void**)&c->Gpart, grows * (k + 2) * sizeof(double)));
     CR(hipMemsetAsync(c->Gpart, 0, grows * (k + 2) * sizeof(double), c->stream));
     CR(hipMalloc((void**)&c->XYpart, (size_t)k * c->xy_stride * f8));
@@ -1640,7 +1782,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkbar, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -2888,6 +3030,13 @@ rri_status rri_comm_stats(rri_ctx* c, int32_t* rank, int32_t* world, int64_t* al
 }
 
 // ---- measurement ---------------------------------------------------------------------------------------------
+rri_status rri_onchip_info(rri_ctx* c, int32_t* eligible, int64_t* launches) {
+    CHECK_CTX(c);
+    if (eligible) *eligible = (c->have_X && c->have_params && onchip_ok(c)) ? 1 : 0;
+    if (launches) *launches = c->onchip_launches;
+    return RRI_OK;
+}
+
 rri_status rri_timing_enable(rri_ctx* c, int32_t on) {
     CHECK_CTX(c);
     c->timing = on < 0 ? 0 : on;

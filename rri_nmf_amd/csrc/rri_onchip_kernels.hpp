@@ -1,0 +1,518 @@
+// rri_onchip_kernels.hpp -- the plain (unweighted, Gram-form) sweep for problems whose X fits the chip's REGISTERS.
+//
+// A 10000 x 1000 fp32 X is 40 MB: 156 KB per CU of an MI355X, against 512 KB of vector registers and 160 KB of LDS per
+// CU.  At that size the launch-per-phase schedule (k_trow_small, k_pass, k_wcol: three dependent launches per topic
+// step, 22-24 us) spends its time on launch latencies and on re-reading a cache-resident X, not on work.  Here ONE
+// persistent kernel -- one 512-thread workgroup per CU (two waves per SIMD, 256 registers each), all co-resident --
+// loads its rows of X into registers once and runs whole sweeps; what crosses workgroups goes through small arrays on
+// the memory side and two flag hand-overs per topic step:
+//
+//   every workgroup b   rows [b rows_wg, (b+1) rows_wg) of X and W   (X: registers, W: LDS; the global k-major W kept current)
+//   worker w < NA       also columns [w CWA, (w+1) CWA) of T         (all k rows of that slice in LDS); NA = ceil(LD / CWA)
+//
+//   phase B (t)  all    T T[t]^T = sum_w mkP[w], row checks (nmf.py:751-769), T[t,:] into registers, y = X t for the own
+//                       rows, W-column update (nmf.py:464-469, 728-734); then for tn = t+1:
+//                       mkZ[b] = w_tn^T X, mkG[b] = (w_tn^T W, ||w_tn||^2, column sum of the update) over the own rows
+//                       -> flagB[b]; the workers wait for all G of them, the others go on to wait for the workers
+//   phase A (tn) workers  g = sum_b mkG[b], column check (nmf.py:471-476), z_j = sum_b mkZ[b][j], numer_T, qf_min for the
+//                       own columns (nmf.py:437-447, 670-676) -> T[tn, slice], mkP[w] = partial T T[tn]^T and row sum
+//                       -> flagA[w] (top bit: the step halts); everybody waits for the NA of them
+//
+// Only NA workgroups read the G x (k+2) Gram partials and everybody reads NA x (k+1) Gram partials of T: with every
+// workgroup reducing everything itself the partial sums alone moved 23 MB per topic step through the memory side, more
+// than half of the X that no longer moves.
+//
+// Wave layout of a workgroup: CG column groups of 256 columns x RG = 8 / CG row groups; lane l of a wave holds the 4
+// adjacent columns cg*256 + 4l .. +3 (one 16-byte load per row) of the rows rg, rg + RG, ... of the workgroup's block:
+// RPW float4 registers.  Row dots are lane-local over 4 columns, 8 rows at a time through a wave-private LDS tile, and CG
+// partials per row meet in LDS; column sums are lane-local over the rows, RG partials per column meet in LDS.  All sums
+// float64, fixed order.
+//
+// Same arithmetic as the launch-per-phase kernels (same branches of qf_min, same checks, same halt protocol:
+// DevState.halt with the position of the detecting step), another order of the row / column partial sums.
+// Only the "light" configuration: no simplex projection of T per iteration, both halves free, 2 <= k <= 64.
+//
+// Hand-overs (tools/barrier_probe.hip, profiles/r02_grid_barrier_variants.log): a workgroup stores the number of the
+// step in its flag; one wave of each waiting workgroup polls the flags it depends on.  Everything that crosses workgroups
+// -- the flags, mkZ / mkG / mkP and the T row of the step -- is written and read with agent-scope accesses (they go to the
+// memory side, past the per-XCD L2s), so no L2 write-back / invalidate is needed: 4.1 us per grid-wide barrier against
+// 7.9 us for a counter with release / acquire fences and 22 us when every wave issues the acquire.  The number of polls
+// is BOUNDED: a grid that cannot make progress (workgroups not co-resident) raises an abort word that every poll also
+// reads, so every wave reaches the end of the kernel and the host sees HALT_ERR_GRID_SYNC instead of a hang.
+#pragma once
+#include "rri_kernels.hpp"
+
+namespace rri {
+
+enum { HALT_ERR_GRID_SYNC = -8 };
+constexpr int ONCHIP_THREADS = 512, ONCHIP_WAVES = ONCHIP_THREADS / 64;
+constexpr int ONCHIP_CWA = 32;          // columns of T per worker
+constexpr int ONCHIP_PG = ONCHIP_THREADS / ONCHIP_CWA;   // groups of workgroup partials in the column-sum reduction
+
+struct OnchipArgs {
+    const float* X; i64 ldx; int n, d, LD, k;
+    double* Wt; i64 ldw; double* T; i64 ldt;
+    double* mkZ;                   // [G][LD]    column-sum partials of the carried topic
+    double* mkG;                   // [k+2][G]   Gram-row partials | ||w||^2 | column sum of the last update, entry-major
+    double* mkP;                   // [k+1][64]  T T[t]^T partials | row sum of the new T row, entry-major (NA <= 64 workers)
+    double* xyp; int xy_stride;    // <w_t, X t_t> partials for the objective (XYpart[t * xy_stride + b])
+    unsigned* bar;                 // [0] abort word, [64 + w] flagA of worker w, [64 + 64 + b] flagB of workgroup b (zero at launch)
+    int G, NA, rows_wg, CG, RG, kS;
+    int s0, t0, ph0, s_end;        // cursor (sweep, topic, phase) and end sweep (exclusive)
+    int skip_row_finish;           // a resumed W half whose T-row checks already ran (after a T-row reset)
+    unsigned spin_limit;
+    long long* dbg;                // diagnostics build only: [2][16] accumulated 100 MHz ticks per section (workgroup 0, workgroup G-1)
+    KParams p; DevState* st;
+};
+
+#define RRI_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, RRI_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, RRI_AGENT));
+}
+
+// this workgroup's data of the step is on the memory side: publish `value` in `mine`
+__device__ __forceinline__ void onchip_signal(unsigned* mine, unsigned value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's agent-scope stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(mine, value, __ATOMIC_RELAXED, RRI_AGENT);
+}
+// wait until the `count` flags at `flags` have reached `epoch` (low 31 bits).  Returns 0 = go on, 1 = a flag carries the
+// halt bit, 2 = the grid gave up.  Called by every thread; wave 0 polls.
+__device__ __forceinline__ int onchip_wait(unsigned* bar, const unsigned* flags, int count, unsigned epoch, unsigned spin_limit) {
+    __shared__ int verdict_sh;
+    if (threadIdx.x < 64) {
+        int verdict = 0;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            unsigned top = 0u;
+            for (int q = threadIdx.x; q < count; q += 64) {
+                const unsigned f = __hip_atomic_load(flags + q, __ATOMIC_RELAXED, RRI_AGENT);
+                ok = ok && ((f & 0x7fffffffu) >= epoch);
+                top |= f & 0x80000000u;
+            }
+            if (__all(ok)) { verdict = __any(top != 0u) ? 1 : 0; break; }
+            if (__hip_atomic_load(bar, __ATOMIC_RELAXED, RRI_AGENT) != 0u) { verdict = 2; break; }
+            if (++spins > spin_limit) {
+                if (threadIdx.x == 0) __hip_atomic_store(bar, 1u, __ATOMIC_RELAXED, RRI_AGENT);
+                verdict = 2;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (threadIdx.x == 0) verdict_sh = verdict;
+    }
+    __syncthreads();
+    const int v = verdict_sh;
+    __syncthreads();                     // verdict_sh is rewritten by the next wait
+    return v;
+}
+
+// sums over `np` workgroup partials part[q * stride + e] for the entries e = wave, wave + 8, ... < ne, into out[e]: the
+// loads of up to 3 entries (4 partials per lane each) are in flight together -- one round trip for k <= 22 -- and every
+// workgroup adds in the same order
+// (entry-major arrays: the np partials of an entry are contiguous, `stride` doubles per entry -- with workgroup-major rows every
+// 8-byte load of a partial touched a sector of its own, eight times the bytes)
+__device__ __forceinline__ void onchip_entry_sums(const double* __restrict__ part, int stride, int ne, int np, double* out,
+                                                  int wave, int lane) {
+    constexpr int EB = 3;
+    for (int e0 = wave; e0 < ne; e0 += ONCHIP_WAVES * EB) {
+        double acc[EB];
+#pragma unroll
+        for (int m = 0; m < EB; ++m) acc[m] = 0.0;
+#pragma unroll 1
+        for (int q0 = lane; q0 < np; q0 += 256) {
+            double v[EB][4];
+#pragma unroll
+            for (int m = 0; m < EB; ++m) {
+                const int e = e0 + ONCHIP_WAVES * m;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + 64 * u;
+                    v[m][u] = (e < ne && q < np) ? ld_agent(part + (unsigned)(e * stride + q)) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < EB; ++m)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m] += v[m][u];
+        }
+#pragma unroll
+        for (int m = 0; m < EB; ++m) {
+            const int e = e0 + ONCHIP_WAVES * m;
+            const double tot = wave_sum<double>(acc[m]);
+            if (lane == 0 && e < ne) out[e] = tot;
+        }
+    }
+}
+
+// DBG: sections of a topic step timed by thread 0 of workgroup 0 (a worker) and of the last workgroup (RRI_ONCHIP_TIMING,
+// tools/onchip_probe.py): 0 phase A loads, 1 phase A rest + signal, 2 wait for the workers, 3 phase B loads, 4 row dots,
+// 5 W update, 6 carry, 7 hand-over to the workers
+template <int RPW, bool DBG = false>
+__global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) {
+    constexpr int NTH = ONCHIP_THREADS, NWV = ONCHIP_WAVES, CWA = ONCHIP_CWA, PG = ONCHIP_PG;
+    DevState* st = a.st;
+    if (st->halt) return;
+    long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long dlast = DBG ? wall_clock64() : 0;
+#define RRI_STAMP(i)                                                           \
+    do {                                                                       \
+        if (DBG && threadIdx.x == 0) {                                         \
+            const long long now_ = wall_clock64();                             \
+            dacc[i] += now_ - dlast;                                           \
+            dlast = now_;                                                      \
+        }                                                                      \
+    } while (0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, G = a.G, NA = a.NA, k = a.k, kS = a.kS, CG = a.CG, RG = a.RG;
+    const int cg = wave % CG, rg = wave / CG;
+    const int col0 = cg * 256 + lane * 4;
+    const int row0 = b * a.rows_wg;
+    const int rows_here = max(0, min(a.rows_wg, a.n - row0));
+    const bool worker = b < NA;
+    const int j0 = b * CWA;                                 // first column of a worker's T slice
+    const KParams p = a.p;
+    unsigned* flagA = a.bar + 64;
+    unsigned* flagB = a.bar + 128;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* Wl = reinterpret_cast<double*>(smem);           // [rows_wg][kS]   own rows of W
+    double* Tl = Wl + (size_t)a.rows_wg * kS;               // [k][CWA]        a worker's column slice of T
+    double* gsh = Tl + (size_t)k * CWA;                     // [k + 2]
+    double* tts = gsh + k + 2;                              // [k + 1]
+    double* zred = tts + k + 1;                             // [PG][CWA]       partial column sums of a worker
+    double* ysh = zred + PG * CWA;                          // [CG][rows_wg]
+    double* xyl = ysh + (size_t)CG * a.rows_wg;             // [rows_wg]
+    double* zsh = xyl + a.rows_wg;                          // [RG][CG * 256] = 8 x 256
+    double* tiles = zsh + NWV * 256;                        // [8 waves][8 x 72]   row-sum tiles (wave_rowsum8)
+    const int LDp = CG * 256;
+    double* tile = tiles + wave * (8 * 72);
+
+    // ---- residents: X rows -> registers, W rows and (workers) the T slice -> LDS ------------------------------------
+    float xr[RPW][4];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int lr = rg + RG * r;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lr < rows_here && col0 < a.LD) v = *reinterpret_cast<const f32x4*>(a.X + (i64)(row0 + lr) * a.ldx + col0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xr[r][c] = v[c];
+    }
+    // X stays fp32 in the registers and is widened where it is used: the compiler must not hoist the conversions out of
+    // the topic loop (it would keep a float64 copy of every element: three times the registers)
+    auto keep_fp32 = [&]() {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(xr[r][0]), "+v"(xr[r][1]), "+v"(xr[r][2]), "+v"(xr[r][3]));
+    };
+    for (int e = tid; e < rows_here * k; e += NTH) {
+        const int l = e / rows_here, i = e - l * rows_here;  // k-major global copy: consecutive threads, consecutive rows
+        Wl[(size_t)i * kS + l] = a.Wt[(i64)l * a.ldw + row0 + i];
+    }
+    if (worker)
+        for (int e = tid; e < k * CWA; e += NTH) {
+            const int l = e / CWA, jl = e - l * CWA;
+            Tl[e] = (j0 + jl < a.d) ? a.T[(i64)l * a.ldt + j0 + jl] : 0.0;
+        }
+    __syncthreads();
+
+    unsigned epoch = 0;       // number of the last hand-over; advances identically in every workgroup
+
+    // column sums and Gram-row partials of topic tn over the own rows -> mkZ[b], mkG[b]; tsum >= 0: also the column sum
+    // of the W column tsum that has just been updated (the pending check of nmf.py:471-476)
+    auto carry = [&](int tn, int tsum) {
+        keep_fp32();
+        double za[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int lr = rg + RG * r;
+            if (lr < rows_here) {
+                const double wn = Wl[(size_t)lr * kS + tn];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) za[c] = fma(wn, (double)xr[r][c], za[c]);
+            }
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows' conversions live at a time, not all RPW
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zsh[(size_t)rg * LDp + col0 + c] = za[c];
+        __syncthreads();
+#pragma unroll 1
+        for (int j = tid; j < a.LD; j += NTH) {
+            double zq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zq[q] = q < RG ? zsh[(size_t)q * LDp + j] : 0.0;
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < RG) s += zq[q];
+            st_agent(a.mkZ + (unsigned)(b * a.LD + j), s);
+        }
+#pragma unroll 1
+        for (int e = wave; e < k + 2; e += NWV) {
+            double acc = 0.0;
+#pragma unroll 1
+            for (int i = lane; i < rows_here; i += 64) {
+                const double wn = Wl[(size_t)i * kS + tn];
+                if (e < k) acc = fma(wn, Wl[(size_t)i * kS + e], acc);
+                else if (e == k) acc = fma(wn, wn, acc);
+                else if (tsum >= 0) acc += Wl[(size_t)i * kS + tsum];
+            }
+            acc = wave_sum<double>(acc);
+            if (lane == 0) st_agent(a.mkG + (unsigned)(e * G + b), acc);
+        }
+    };
+    // phase B of every workgroup is done -> flagB; the workers wait for all of them
+    auto hand_to_workers = [&]() -> int {
+        epoch += 1u;
+        onchip_signal(flagB + b, epoch);
+        return worker ? onchip_wait(a.bar, flagB, G, epoch, a.spin_limit) : 0;
+    };
+
+    bool have_carry = false;
+    int chk = 0, tprev = -1;
+    for (int s = a.s0; s < a.s_end; ++s) {
+        for (int t = (s == a.s0) ? a.t0 : 0; t < k; ++t) {
+            const int ph = (s == a.s0 && t == a.t0) ? a.ph0 : 0;
+            const bool update_T = ph == 0;
+            int mode = 0;
+            if (update_T && !have_carry) {
+                carry(t, -1);
+                if (hand_to_workers() == 2) goto sync_failed;
+            }
+            // ---------------- phase A (workers): T row t on the own column slice -----------------------------------
+            RRI_STAMP(7);
+            unsigned halt_bit = 0u;
+            if (worker) {
+                if (update_T) {
+                    // the partials of the own columns: thread = (column jl, group pg of workgroups pg, pg + PG, ...)
+                    const int jl = tid % CWA, pg = tid / CWA;
+                    double zp[16];
+                    const bool col_ok = j0 + jl < a.LD;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int q = pg + PG * u;
+                        zp[u] = (col_ok && q < G) ? ld_agent(a.mkZ + (unsigned)(q * a.LD + j0 + jl)) : 0.0;
+                    }
+                    onchip_entry_sums(a.mkG, G, k + 2, G, gsh, wave, lane);
+                    double zacc = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) zacc += zp[u];
+#pragma unroll 1
+                    for (int q = pg + PG * 16; q < G; q += PG) zacc += col_ok ? ld_agent(a.mkZ + (unsigned)(q * a.LD + j0 + jl)) : 0.0;
+                    zred[pg * CWA + jl] = zacc;
+                    __syncthreads();
+                    RRI_STAMP(0);
+                    const double nw = gsh[k];
+                    int code = 0;
+                    if (chk) {
+                        const double sw = gsh[k + 1];
+                        const bool ev = (sw <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+                        const bool err = !ev && !(sw > 0.0);
+                        if (ev || err) {
+                            code = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+                            if (b == 0 && tid == 0) { st->halt = code; st->halt_topic = tprev; st->halt_sweep = s; st->halt_pos = t; }
+                        }
+                    }
+                    const double c = nw + p.reg_t_l2;          // denom = nw + reg_t_l2 (nmf.py:438)
+                    if (code == 0 && !(c > 0.0)) {             // scalar c <= 0 without a projection (optimization.py:60-67)
+                        if (p.has_trs && p.t_row_sum != 0.0) mode = 1;
+                        else {
+                            code = HALT_ERR_UNBOUNDED;
+                            if (b == 0 && tid == 0) { st->halt = code; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t; }
+                        }
+                    }
+                    if (code != 0) halt_bit = 0x80000000u;     // every worker takes the same verdict from the same sums
+                    else if (tid < CWA && j0 + tid < a.d) {
+                        double z = 0.0;
+#pragma unroll 1
+                        for (int q = 0; q < PG; ++q) z += zred[q * CWA + tid];
+                        double acc = 0.0;
+#pragma unroll 1
+                        for (int l0 = 0; l0 < k; l0 += 8) {        // 8 LDS reads in flight; the terms still added in topic order
+                            double gv[8], tvv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int l = l0 + q;
+                                gv[q] = (l < k && l != t) ? gsh[l] : 0.0;
+                                tvv[q] = (l < k) ? Tl[l * CWA + tid] : 0.0;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (l0 + q < k && l0 + q != t) acc = fma(gv[q], tvv[q], acc);
+                        }
+                        const double numer = (z - acc) - p.reg_t_l1;
+                        double x;
+                        if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
+                        else x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
+                        Tl[t * CWA + tid] = x;
+                        st_agent(a.T + (i64)t * a.ldt + j0 + tid, x);
+                    }
+                    __syncthreads();
+                    if (b == 0 && tid == 0 && code == 0) st->tmode = mode;
+                }
+                if (halt_bit == 0u) {
+                    // T T[t]^T over the own slice; [k] = sum of the row.  Thread = (entry e, quarter of the 32 columns): 8 LDS
+                    // reads in flight each, the four quarters of an entry sit in adjacent lanes and are added in order
+                    for (int e0 = 0; e0 < k + 1; e0 += NTH / 4) {
+                        const int e = e0 + (tid >> 2), part = tid & 3;
+                        double xv[8], lv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int jl = part * 8 + q;
+                            xv[q] = Tl[t * CWA + jl];
+                            lv[q] = (e < k) ? Tl[e * CWA + jl] : 1.0;
+                        }
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc = fma(lv[q], xv[q], acc);
+                        const double a1 = __shfl_down(acc, 1, 4), a2 = __shfl_down(acc, 2, 4), a3 = __shfl_down(acc, 3, 4);
+                        if (part == 0 && e < k + 1) st_agent(a.mkP + (unsigned)(e * 64 + b), ((acc + a1) + a2) + a3);
+                    }
+                }
+                epoch += 1u;
+                onchip_signal(flagA + b, epoch | halt_bit);
+                RRI_STAMP(1);
+            } else {
+                epoch += 1u;
+            }
+            {
+                const int v = onchip_wait(a.bar, flagA, NA, epoch, a.spin_limit);
+                if (v == 2) goto sync_failed;
+                if (v == 1) return;                        // the workers found an event or an error: DevState says which
+            }
+            RRI_STAMP(2);
+            // mode of the T row for the diagnostics below: only workgroup 0 (a worker) reports it
+
+            // ---------------- phase B: row checks, W column t on the own rows, carry of topic t + 1 ---------------
+            {
+                double tv[4] = {0.0, 0.0, 0.0, 0.0};
+                if (col0 < a.LD) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tv[c] = ld_agent(a.T + (unsigned)(t * (int)a.ldt + col0 + c));
+                }
+                onchip_entry_sums(a.mkP, 64, k + 1, NA, tts, wave, lane);
+                __syncthreads();
+                RRI_STAMP(3);
+                const bool row_checks = update_T || !a.skip_row_finish;
+                if (row_checks) {                          // _project_and_check_reset_t without a projection (nmf.py:751-769)
+                    const double ps = tts[k];
+                    if (b == 0 && tid == 0) {
+                        st->nt1 = (mode == 0) ? ps : 1.0;
+                        st->sumT = ps;
+                    }
+                    if (!(ps > 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0) {
+                        if (b == 0 && tid == 0) {
+                            st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t;
+                        }
+                        return;                            // every workgroup: the same sums, the same verdict
+                    }
+                }
+                const double cden = tts[t] + p.reg_w_l2;   // denom = nt + reg_w_l2 (nmf.py:465)
+                int wmode = 0;
+                if (!(cden > 0.0)) {
+                    if (p.has_wrs && p.w_row_sum != 0.0) wmode = 1;
+                    else {
+                        if (b == 0 && tid == 0) {
+                            st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t;
+                        }
+                        return;
+                    }
+                }
+                if (b == 0 && tid == 0) st->nt = tts[t];
+                keep_fp32();
+                // row dots of the own rows, 8 rows per round through the wave's LDS tile (wave_rowsum8)
+#pragma unroll
+                for (int r0 = 0; r0 < RPW; r0 += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double part = 0.0;
+                        if (r0 + u < RPW) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) part = fma((double)xr[r0 + u < RPW ? r0 + u : 0][c], tv[c], part);
+                        }
+                        wave_rowsum8_park(tile, u, lane, part);
+                    }
+                    const double tot = wave_rowsum8_finish(tile, lane);
+                    const int lr = rg + RG * (r0 + (lane >> 3));
+                    if ((lane & 7) == 0 && r0 + (lane >> 3) < RPW && lr < rows_here) ysh[(size_t)cg * a.rows_wg + lr] = tot;
+                }
+                __syncthreads();
+                RRI_STAMP(4);
+                if (tid < rows_here) {
+                    double y = 0.0;
+#pragma unroll 1
+                    for (int q = 0; q < CG; ++q) y += ysh[(size_t)q * a.rows_wg + tid];
+                    double dot = 0.0;
+#pragma unroll 1
+                    for (int l0 = 0; l0 < k; l0 += 8) {            // 8 LDS reads in flight; the terms still added in topic order
+                        double wv[8], sv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int l = l0 + q;
+                            wv[q] = (l < k) ? Wl[(size_t)tid * kS + l] : 0.0;
+                            sv[q] = (l < k && l != t) ? tts[l] : 0.0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (l0 + q < k && l0 + q != t) dot = fma(wv[q], sv[q], dot);
+                    }
+                    const double numer = (y - dot) - p.reg_w_l1;
+                    double wnew;
+                    if (wmode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
+                    else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
+                    Wl[(size_t)tid * kS + t] = wnew;
+                    a.Wt[(i64)t * a.ldw + row0 + tid] = wnew;
+                    xyl[tid] = wnew * y;
+                }
+                __syncthreads();
+                if (wave == 0) {                           // <w_t, X t_t> over the own rows: the objective's cross term
+                    double acc = 0.0;
+#pragma unroll 1
+                    for (int i = lane; i < rows_here; i += 64) acc += xyl[i];
+                    acc = wave_sum<double>(acc);
+                    if (lane == 0) a.xyp[(i64)t * a.xy_stride + b] = acc;
+                }
+                RRI_STAMP(5);
+                carry((t + 1) % k, t);
+                RRI_STAMP(6);
+                chk = 1;
+                tprev = t;
+                have_carry = true;
+            }
+            if (hand_to_workers() == 2) goto sync_failed;
+        }
+    }
+    RRI_STAMP(7);
+    if (DBG && a.dbg && tid == 0 && (b == 0 || b == G - 1))
+        for (int i = 0; i < 8; ++i) a.dbg[(b == 0 ? 0 : 16) + i] = dacc[i];
+    // the column check of the last W update of the call (position of the next step: sweep s_end, topic 0): workgroup 0 is
+    // a worker and has waited for every workgroup's partials
+    if (chk && b == 0) {
+        const double v = [&]() {
+            double acc = 0.0;
+#pragma unroll 1
+            for (int q = lane; q < G; q += 64) acc += ld_agent(a.mkG + (unsigned)((k + 1) * G + q));
+            return wave_sum<double>(acc);
+        }();
+        if (tid == 0) {
+            const bool ev = (v <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+            const bool err = !ev && !(v > 0.0);
+            if (ev || err) {
+                st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+                st->halt_topic = tprev; st->halt_sweep = a.s_end; st->halt_pos = 0;
+            }
+        }
+    }
+    return;
+sync_failed:
+    if (b == 0 && tid == 0 && st->halt == 0) {
+        st->halt = HALT_ERR_GRID_SYNC; st->halt_topic = -1; st->halt_sweep = 0; st->halt_pos = 0;
+    }
+}
+
+#undef RRI_STAMP
+
+}  // namespace rri

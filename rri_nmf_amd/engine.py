@@ -571,6 +571,12 @@ class RRIEngine(object):
         self._check(self._lib.rri_timing_read(self._h, int(kernel_id), C.byref(cnt), C.byref(ms)))
         return int(cnt.value), float(ms.value)
 
+    def onchip_info(self):
+        """(would the next sweep() run as the register-resident persistent launch, how many such launches so far)"""
+        el, n = C.c_int32(0), C.c_int64(0)
+        self._check(self._lib.rri_onchip_info(self._h, C.byref(el), C.byref(n)))
+        return bool(el.value), int(n.value)
+
     def synchronize(self):
         self._check(self._lib.rri_synchronize(self._h))
 

@@ -1,0 +1,174 @@
+"""The register-resident persistent sweep (rri_onchip_kernels.hpp): launch-bound sizes whose fp32 X fits the chip's
+registers run rri_sweep as ONE launch with two hand-overs between workgroups per topic step.  Same arithmetic as the launch-per-phase
+kernels (nmf.py:437-476, 670-676, 728-734), another order of the partial sums:
+
+  * against the launch-per-phase schedule (RRI_ONCHIP=0) on the same inputs: 1e-9, every wave layout (d <= 256 / 512 /
+    1024), ragged shapes, k = 2 and k = 22, regularisation, the c <= 0 branches with bounds;
+  * against the CPU oracle (the reference's operation order): 2e-9, BASELINE's 10000 x 1000, k = 20 included;
+  * reset events of both kinds through nmf(): the same events at the same steps, the same result;
+  * what the path does not cover (float64 storage, per-iteration projection of T, fixed halves, k > 22) reports not eligible
+    and runs as before.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import relfro
+from rri_nmf_amd.synthetic import planted_X, scaled_init
+
+pytestmark = pytest.mark.gpu
+
+
+def engine(*a, **kw):
+    from rri_nmf_amd.engine import RRIEngine
+    return RRIEngine(*a, **kw)
+
+
+class onchip(object):
+    """RRI_ONCHIP for the handles created inside (rri_create reads the environment)"""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get('RRI_ONCHIP')
+        os.environ['RRI_ONCHIP'] = '1' if self.on else '0'
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop('RRI_ONCHIP', None)
+        else:
+            os.environ['RRI_ONCHIP'] = self.old
+
+
+def run(X, W0, T0, sweeps, on, objective=False, **params):
+    n, d = X.shape
+    k = W0.shape[1]
+    with onchip(on), engine(n, d, k, dtype=np.float32) as e:
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**params)
+        eligible, before = e.onchip_info()
+        assert eligible == bool(on), (eligible, on)
+        objs = []
+        for _ in range(sweeps if objective else 1):
+            e.sweep(1 if objective else sweeps)
+            if objective:
+                objs.append(e.objective())
+        launches = e.onchip_info()[1] - before
+        assert (launches > 0) == bool(on), launches
+        return e.get_W(), e.get_T(), np.array(objs), e.n_resets_used
+
+
+SHAPES = [(50, 30, 3), (700, 200, 2), (1501, 333, 6), (2600, 512, 7), (4096, 1024, 5), (5003, 1000, 22), (10000, 1000, 20),
+          (300, 700, 4), (10240, 1024, 8)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_onchip_equals_launch_per_phase(shape):
+    n, d, k = shape
+    X = planted_X(n, d, min(k, 20), seed=n + d, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=5)
+    Wa, Ta, oa, _ = run(X, W0, T0, 3, True, objective=True)
+    Wb, Tb, ob, _ = run(X, W0, T0, 3, False, objective=True)
+    # the two paths add the same terms in another order: what that leaves after 3 sweeps grows with k (the Gauss-Seidel
+    # chain of a sweep from a random start amplifies a rounding difference topic by topic; 2e-11 at k = 20)
+    assert relfro(Wa, Wb) < 1e-9 and relfro(Ta, Tb) < 1e-9, (relfro(Wa, Wb), relfro(Ta, Tb))
+    # after an on-chip sweep the objective comes from the cross terms the kernel left (no pass over X), as after k_wcol
+    assert np.allclose(oa, ob, rtol=1e-10), (oa, ob)
+    assert np.all(np.diff(oa) <= 1e-9 * oa[0])
+
+
+@pytest.mark.parametrize('params', [
+    dict(reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03),
+    dict(t_row_sum=1.0),                                   # an upper bound without a projection (the RS flags' T side)
+    dict(t_row_sum=1.0, w_row_sum=1.0, reset_topic_method=None),
+    dict(reset_topic_method=None),
+])
+def test_flag_sets(params):
+    n, d, k = 1800, 640, 5
+    X = planted_X(n, d, k, seed=11, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=12)
+    Wa, Ta, _, _ = run(X, W0, T0, 4, True, **params)
+    Wb, Tb, _, _ = run(X, W0, T0, 4, False, **params)
+    assert relfro(Wa, Wb) < 1e-11 and relfro(Ta, Tb) < 1e-11, (relfro(Wa, Wb), relfro(Ta, Tb))
+
+
+@pytest.mark.parametrize('shape', [(1501, 333, 6), (10000, 1000, 20)])
+def test_against_the_cpu_oracle(shape):
+    from oracle import rri_oracle as orc
+    n, d, k = shape
+    X = planted_X(n, d, k, seed=21, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=22)
+    sweeps = 5
+    Wa, Ta, _, _ = run(X, W0, T0, sweeps, True)
+    Wc, Tc = W0.astype(np.float64).copy(), T0.astype(np.float64).copy()
+    orc.plain_sweeps(np.asarray(X, dtype=np.float64), Wc, Tc, sweeps)
+    assert relfro(Wa, Wc) < 2e-9 and relfro(Ta, Tc) < 2e-9, (relfro(Wa, Wc), relfro(Ta, Tc))
+    assert np.array_equal(np.argmax(Wa, 1), np.argmax(Wc, 1))
+
+
+@pytest.mark.parametrize('flags', [dict(t_row_sum=1.0, reg_w_l1=1e6), dict(t_row_sum=1.0, reg_t_l1=1e6),
+                                   dict(t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random', fix_reset_seed=True)])
+def test_reset_events_through_nmf(flags):
+    """columns / rows driven to zero: the events are raised by the persistent kernel at the step that finds them, resolved
+    by the host (nmf.py:751-816) and the run resumed in the middle of a sweep"""
+    from rri_nmf_amd import nmf as nmf_mod
+    n, d, k = 600, 200, 4
+    X = planted_X(n, d, k, seed=31, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=32)
+    out = []
+    for on in (True, False):
+        with onchip(on):
+            np.random.seed(0)
+            out.append(nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=2, eps_stop=-1, compute_obj_each_iter=True,
+                                   dtype=np.float32, **flags))
+    a, b = out
+    assert a['n_resets_used'] == b['n_resets_used'] >= k
+    assert relfro(a['W'], b['W']) < 1e-10 and relfro(a['T'], b['T']) < 1e-10
+    assert np.allclose(a['obj_history'], b['obj_history'], rtol=1e-10)
+
+
+def test_dead_column_without_resets_is_the_reference_error():
+    n, d, k = 400, 150, 3
+    X = planted_X(n, d, k, seed=41, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=42)
+    from rri_nmf_amd import nmf as nmf_mod
+    for on in (True, False):
+        with onchip(on), pytest.raises(AssertionError, match='sums to 0'):
+            nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=2, eps_stop=-1, reg_w_l1=1e6, reset_topic_method=None,
+                        dtype=np.float32)
+
+
+def test_what_is_not_covered_stays_on_the_launch_per_phase_path():
+    n, d, k = 900, 300, 4
+    X = planted_X(n, d, k, seed=51, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=52)
+    for dtype, params in ((np.float64, dict()), (np.float32, dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+                          (np.float32, dict(fix_T=True)), (np.float32, dict(fix_W=True))):
+        with onchip(True), engine(n, d, k, dtype=dtype) as e:
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**params)
+            assert e.onchip_info() == (False, 0)
+            e.sweep(1)
+            assert e.onchip_info() == (False, 0)
+    with onchip(True), engine(n, d, 23, dtype=np.float32) as e:            # more Gram entries than one round of loads takes
+        e.set_params()
+        e.upload_X(X)
+        assert e.onchip_info()[0] is False
+    with onchip(True), engine(40000, 1024, 4, dtype=np.float32) as e:      # too many rows per CU for the registers
+        e.set_params()
+        e.upload_X(np.zeros((40000, 1024), dtype=np.float32))
+        assert e.onchip_info()[0] is False
+
+
+def test_many_sweeps_in_one_launch_and_a_later_call_continue_the_same_run():
+    n, d, k = 3000, 800, 6
+    X = planted_X(n, d, k, seed=61, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=62)
+    with onchip(True), engine(n, d, k, dtype=np.float32) as e:
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+        e.sweep(7)
+        e.sweep(3)
+        Wa, Ta = e.get_W(), e.get_T()
+        assert e.onchip_info()[1] == 2
+    Wb, Tb, _, _ = run(X, W0, T0, 10, False)
+    assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10

@@ -1410,12 +1410,12 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     if (!onchip_geometry(c, &g)) return false;
     const int k = c->k;
     if (!c->mkZ) {
-        if (hipMalloc((void**)&c->mkZ, (size_t)g.G * c->LD * 8) != hipSuccess) { c->mkZ = nullptr; return false; }
-        if (hipMalloc((void**)&c->mkG, (size_t)g.G * (k + 2) * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->mkZ, (size_t)2 * g.G * c->LD * 8) != hipSuccess) { c->mkZ = nullptr; return false; }
+        if (hipMalloc((void**)&c->mkG, (size_t)2 * g.G * (k + 2) * 8) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkP, (size_t)64 * (k + 1) * 8) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkbar, (size_t)(128 + g.G) * sizeof(unsigned)) != hipSuccess) return false;
-        (void)hipMemsetAsync(c->mkZ, 0, (size_t)g.G * c->LD * 8, c->stream);
-        (void)hipMemsetAsync(c->mkG, 0, (size_t)g.G * (k + 2) * 8, c->stream);
+        (void)hipMemsetAsync(c->mkZ, 0, (size_t)2 * g.G * c->LD * 8, c->stream);
+        (void)hipMemsetAsync(c->mkG, 0, (size_t)2 * g.G * (k + 2) * 8, c->stream);
         (void)hipMemsetAsync(c->mkP, 0, (size_t)64 * (k + 1) * 8, c->stream);
     }
     if (!c->mkG || !c->mkP || !c->mkbar) return false;

@@ -485,9 +485,8 @@ def main():
             elif resid_sched:
                 keys = [kk for kk in pm if 'k_pass<float, true, true, 2' in kk]
                 per_launch = 1.0
-            elif onchip:    # the profiled command's timed launch (the warm-up launch is the other one: averaged)
-                keys = [kk for kk in pm if 'k_onchip_sweeps' in kk]
-                per_launch = 1.0
+            elif onchip:    # one launch per call, of whatever --steps was: a per-launch counter of another command says nothing here
+                keys = []
             else:
                 keys = [kk for kk in pm if 'k_pass<float, true, true, 0' in kk]
                 per_launch = 1.0

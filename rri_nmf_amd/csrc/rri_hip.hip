@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1397,12 +1398,20 @@ hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
     if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: occupancy %d per CU (%s), %d CUs\n", per_cu, hipGetErrorString(e), c->n_cu);
     if (e != hipSuccess) return e;
     if ((i64)per_cu * c->n_cu < g.G) return hipErrorCooperativeLaunchTooLarge;     // the hand-overs need every workgroup resident
-    // a cooperative launch: the runtime keeps two such grids (two handles, two streams) from each holding a part of the
-    // device while waiting for the rest
-    OnchipArgs args = a;
-    void* argv[] = {(void*)&args};
-    return hipLaunchCooperativeKernel((const void*)k_onchip_sweeps<RPW, DBG>, dim3(g.G), dim3(ONCHIP_THREADS), argv,
-                                      (unsigned)g.shmem, c->stream);
+    // Two such grids on one device (two handles on two streams) must not each hold a part of the CUs while waiting for the
+    // rest: inside a process every persistent launch waits for the one before it.  (hipLaunchCooperativeKernel gives the
+    // same guarantee from the runtime and worked, but a process that had used it crashed in its exit handlers under
+    // rocprofv3 on ROCm 7.2 -- after the tool had written its results.)  Across processes the bounded polls end the wait.
+    static std::mutex mu;
+    static hipEvent_t last[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    const int dv2 = c->device & 63;
+    if (!last[dv2] && hipEventCreateWithFlags(&last[dv2], hipEventDisableTiming) != hipSuccess) last[dv2] = nullptr;
+    if (last[dv2]) (void)hipStreamWaitEvent(c->stream, last[dv2], 0);
+    hipLaunchKernelGGL((k_onchip_sweeps<RPW, DBG>), dim3(g.G), dim3(ONCHIP_THREADS), g.shmem, c->stream, a);
+    const hipError_t le = hipGetLastError();
+    if (le == hipSuccess && last[dv2]) (void)hipEventRecord(last[dv2], c->stream);
+    return le;
 }
 // sweeps [cur .. run_total) in one launch; false: not launched (the caller takes the launch-per-phase schedule)
 bool enqueue_onchip(rri_ctx* c, Cursor cur) {

@@ -1437,6 +1437,7 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     a.s0 = cur.sweep; a.t0 = cur.topic; a.ph0 = cur.phase; a.s_end = c->run_total;
     a.skip_row_finish = c->skip_row_finish ? 1 : 0;
     a.spin_limit = 2000000u;            // polls of ~1 us: a grid that stands still for seconds gives up (HALT_ERR_GRID_SYNC)
+    if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
     a.p = kparams(c); a.st = c->st;
     a.dbg = nullptr;
     if (getenv("RRI_ONCHIP_TIMING")) {           // diagnostics: per-section ticks of the last launch, printed at the next one

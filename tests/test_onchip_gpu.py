@@ -172,3 +172,20 @@ def test_many_sweeps_in_one_launch_and_a_later_call_continue_the_same_run():
         assert e.onchip_info()[1] == 2
     Wb, Tb, _, _ = run(X, W0, T0, 10, False)
     assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10
+
+
+def test_a_grid_that_cannot_synchronise_returns_an_error_instead_of_hanging(monkeypatch):
+    """the hand-overs poll a bounded number of times; RRI_ONCHIP_SPIN_LIMIT=0 makes the first unsatisfied poll give up:
+    the abort word takes every workgroup to the end of the kernel and the call reports RRI_ERR_HIP"""
+    n, d, k = 3000, 800, 6
+    X = planted_X(n, d, k, seed=71, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=72)
+    monkeypatch.setenv('RRI_ONCHIP_SPIN_LIMIT', '0')
+    with onchip(True), engine(n, d, k, dtype=np.float32) as e:
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+        with pytest.raises(RuntimeError, match='synchronise'):
+            e.sweep(2)
+    monkeypatch.delenv('RRI_ONCHIP_SPIN_LIMIT')
+    Wa, Ta, _, _ = run(X, W0, T0, 2, True)                  # the device and the library are fine afterwards
+    Wb, Tb, _, _ = run(X, W0, T0, 2, False)
+    assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10

@@ -276,9 +276,10 @@ rri_status rri_timing_enable(rri_ctx* ctx, int32_t on);
 rri_status rri_timing_read(rri_ctx* ctx, int32_t kernel_id, int64_t* launches, double* total_ms);
 rri_status rri_synchronize(rri_ctx* ctx);
 /* Launch-bound sizes: when X (fp32) fits the registers of the chip -- up to about 20000 x 1024 -- and the configuration
- * is the plain one (both halves free, no per-iteration projection of T, k in 2..64, one device), rri_sweep / rri_resume
- * run as ONE persistent launch with X resident on chip and two grid barriers per topic step (rri_onchip_kernels.hpp)
- * instead of three launches per topic step; the whole launch is then timed as kernel_id 0.  *eligible: would the next
+ * is the unweighted one with both halves free (plain, or the topic-model flags with T rows projected at every step), k in
+ * 2..22, one device, rri_sweep / rri_resume run as ONE persistent launch with X resident on chip and two (topic model:
+ * three) hand-overs between workgroups per topic step (rri_onchip_kernels.hpp) instead of three or four launches per topic
+ * step; the whole launch is then timed as kernel_id 0.  *eligible: would the next
  * rri_sweep take that path; *launches: how many it has taken on this handle.  RRI_ONCHIP=0 (environment, read by
  * rri_create) switches it off.  Either pointer may be NULL. */
 rri_status rri_onchip_info(rri_ctx* ctx, int32_t* eligible, int64_t* launches);

@@ -30,7 +30,9 @@
 //
 // Same arithmetic as the launch-per-phase kernels (same branches of qf_min, same checks, same halt protocol:
 // DevState.halt with the position of the detecting step), another order of the row / column partial sums.
-// Only the "light" configuration: no simplex projection of T per iteration, both halves free, 2 <= k <= 64.
+// Both halves free, 2 <= k <= 22.  With the topic-model flags (T rows projected onto the simplex at every step) the workers
+// exchange their slices of the closed-form row and each finishes the projection of the whole row: one more hand-over among
+// the 32 workers per step.
 //
 // Hand-overs (tools/barrier_probe.hip, profiles/r02_grid_barrier_variants.log): a workgroup stores the number of the
 // step in its flag; one wave of each waiting workgroup polls the flags it depends on.  Everything that crosses workgroups
@@ -55,6 +57,7 @@ struct OnchipArgs {
     double* mkZ;                   // [2][G][LD]   column-sum partials of the carried topic (two buffers: by the parity of the step that reads)
     double* mkG;                   // [2][k+2][G]  Gram-row partials | ||w||^2 | column sum of the last update, entry-major
     double* mkP;                   // [k+1][64]  T T[t]^T partials | row sum of the new T row, entry-major (NA <= 64 workers)
+    double* xraw;                  // [LD]  the T row before its projection (topic-model flags): slices from the workers
     double* xyp; int xy_stride;    // <w_t, X t_t> partials for the objective (XYpart[t * xy_stride + b])
     unsigned* bar;                 // [0] abort word, [64 + w] flagA of worker w, [64 + 64 + b] flagB of workgroup b (zero at launch)
     int G, NA, rows_wg, CG, RG, kS;
@@ -149,10 +152,40 @@ __device__ __forceinline__ void onchip_entry_sums(const double* __restrict__ par
     }
 }
 
+// Michelot's fixed point for the simplex projection of a row held two elements per thread (v0 = row[tid], v1 = row[tid + 512];
+// -inf where there is none): the same iteration as simplex_theta (rri_kernels.hpp), with the sum and the count of the active
+// set reduced together -- two barriers per iteration instead of eight; every thread returns the same theta
+__device__ __forceinline__ double onchip_simplex_theta(double v0, double v1, double s, double* sh, int* iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double theta = -1.0e300;
+    i64 cnt_prev = -1;
+    int it = 0;
+    for (; it < 2 * ONCHIP_THREADS + 2; ++it) {
+        double sum = 0.0, cnt = 0.0;
+        if (v0 > theta) { sum += v0; cnt += 1.0; }
+        if (v1 > theta) { sum += v1; cnt += 1.0; }
+        sum = wave_sum<double>(sum);
+        cnt = wave_sum<double>(cnt);
+        __syncthreads();                       // sh may still be read from the iteration before
+        if (lane == 0) { sh[wave] = sum; sh[8 + wave] = cnt; }
+        __syncthreads();
+        double S = 0.0, C = 0.0;
+#pragma unroll
+        for (int q = 0; q < ONCHIP_WAVES; ++q) { S += sh[q]; C += sh[8 + q]; }
+        const i64 ci = (i64)C;
+        if (ci == cnt_prev || ci == 0) break;
+        theta = (S - s) / C;
+        cnt_prev = ci;
+    }
+    *iters = it;
+    return theta;
+}
+
 // DBG: sections of a topic step timed by thread 0 of workgroup 0 (a worker) and of the last workgroup (RRI_ONCHIP_TIMING,
 // tools/onchip_probe.py): 0 phase A loads, 1 phase A rest + signal, 2 wait for the workers, 3 phase B loads, 4 row dots,
 // 5 W update, 6 carry, 7 hand-over to the workers
-template <int RPW, bool DBG = false>
+// PROJ: the instantiation for the topic-model flags (the projection stage costs the plain one registers it does not have)
+template <int RPW, bool DBG = false, bool PROJ = false>
 __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) {
     constexpr int NTH = ONCHIP_THREADS, NWV = ONCHIP_WAVES, CWA = ONCHIP_CWA, PG = ONCHIP_PG;
     DevState* st = a.st;
@@ -191,6 +224,10 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     double* tiles = zsh + NWV * 256;                        // [8 waves][8 x 72]   row-sum tiles (wave_rowsum8)
     const int LDp = CG * 256;
     double* tile = tiles + wave * (8 * 72);
+    double* rowsh = tiles + NWV * 8 * 72;                   // [LD]  the whole T row of the step (workers, topic-model flags)
+    double* scratch = rowsh + 1024;                         // [40]  block sums
+    constexpr bool project = PROJ;                          // T rows on the simplex at every step (nmf.py:447, 751-761):
+                                                            // the host picks the instantiation from project_T && has_t_row_sum
 
     // ---- residents: X rows -> registers, W rows and (workers) the T slice -> LDS ------------------------------------
     float xr[RPW][4];
@@ -341,10 +378,12 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         }
                     }
                     const double c = nw + p.reg_t_l2;          // denom = nw + reg_t_l2 (nmf.py:438)
-                    if (code == 0 && !(c > 0.0)) {             // scalar c <= 0 without a projection (optimization.py:60-67)
-                        if (p.has_trs && p.t_row_sum != 0.0) mode = 1;
-                        else {
-                            code = HALT_ERR_UNBOUNDED;
+                    if (code == 0 && !(c > 0.0)) {             // scalar c <= 0 (optimization.py:60-73)
+                        if (project) mode = (p.t_row_sum == 1.0) ? 2 : HALT_ERR_NOT_IMPLEMENTED;     // one-hot at the arg-max
+                        else if (p.has_trs && p.t_row_sum != 0.0) mode = 1;                          // entries at a bound
+                        else mode = HALT_ERR_UNBOUNDED;
+                        if (mode < 0) {
+                            code = mode;
                             if (b == 0 && tid == 0) { st->halt = code; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t; }
                         }
                     }
@@ -370,12 +409,87 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         const double numer = (z - acc) - p.reg_t_l1;
                         double x;
                         if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
-                        else x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
-                        Tl[t * CWA + tid] = x;
-                        st_agent(a.T + (i64)t * a.ldt + j0 + tid, x);
+                        else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
+                        else x = numer;                            // mode 2: the arg-max of the numerator takes it all
+                        if (project) st_agent(a.xraw + (unsigned)(j0 + tid), x);
+                        else {
+                            Tl[t * CWA + tid] = x;
+                            st_agent(a.T + (i64)t * a.ldt + j0 + tid, x);
+                        }
                     }
                     __syncthreads();
                     if (b == 0 && tid == 0 && code == 0) st->tmode = mode;
+                    if (project && code == 0) {
+                        // the closed-form row is complete only across the workers: every worker takes all slices (a hand-over
+                        // among the NA workers) and finishes qf_min for the whole row itself -- Michelot's fixed point for the
+                        // simplex projection, or the one-hot row -- and the checks of _project_and_check_reset_t
+                        // (nmf.py:751-769), exactly as k_trow_final does; all workers come to the same row and verdict
+                        epoch += 1u;
+                        onchip_signal(flagA + b, epoch);
+                        if (onchip_wait(a.bar, flagA, NA, epoch, a.spin_limit) == 2) goto sync_failed;
+                        for (int j = tid; j < a.LD; j += NTH) rowsh[j] = j < a.d ? ld_agent(a.xraw + (unsigned)j) : 0.0;
+                        __syncthreads();
+                        double nx = 1.0, sumT = 0.0;
+                        int iters = 0;
+                        if (mode == 2) {
+                            double mx = -1.0e300;
+                            i64 idx = (i64)0x7fffffffffffffffLL;
+                            for (int j = tid; j < a.d; j += NTH)
+                                if (rowsh[j] > mx) { mx = rowsh[j]; idx = j; }     // ascending j per thread: first index on ties
+                            wave_argmax(mx, idx);
+                            __syncthreads();
+                            if (lane == 0) { scratch[wave] = mx; scratch[8 + wave] = (double)idx; }
+                            __syncthreads();
+                            double bm = scratch[0];
+                            i64 bi = (i64)scratch[8];
+                            for (int q = 1; q < NWV; ++q) {
+                                const double om = scratch[q];
+                                const i64 oi = (i64)scratch[8 + q];
+                                if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+                            }
+                            __syncthreads();
+                            for (int j = tid; j < a.d; j += NTH) rowsh[j] = (j == bi) ? 1.0 : 0.0;
+                        } else {
+                            // LD <= 1024: the row sits two elements per thread in registers from here on
+                            double v0 = tid < a.d ? rowsh[tid] : -1.0e300, v1 = tid + NTH < a.d ? rowsh[tid + NTH] : -1.0e300;
+                            double ps = (tid < a.d ? v0 : 0.0) + (tid + NTH < a.d ? v1 : 0.0);
+                            ps = block_sum(ps, scratch);
+                            nx = ps;
+                            const double th = onchip_simplex_theta(v0, v1, p.t_row_sum, scratch, &iters);
+                            if (tid < a.d) rowsh[tid] = fmax(v0 - th, 0.0);
+                            if (tid + NTH < a.d) rowsh[tid + NTH] = fmax(v1 - th, 0.0);
+                            if (b == 0 && tid == 0) st->theta = th;
+                        }
+                        __syncthreads();
+                        const double w0 = tid < a.d ? rowsh[tid] : -1.0e300, w1 = tid + NTH < a.d ? rowsh[tid + NTH] : -1.0e300;
+                        sumT = (tid < a.d ? w0 : 0.0) + (tid + NTH < a.d ? w1 : 0.0);
+                        sumT = block_sum(sumT, scratch);
+                        if (sumT > 1e-10 || p.reset_method == RESET_NONE) {
+                            if (p.t_row_sum != 0.0 && fabs(sumT - p.t_row_sum) > 1e-15) {     // nmf.py:759-761: project again
+                                int it2 = 0;
+                                const double th = onchip_simplex_theta(w0, w1, p.t_row_sum, scratch, &it2);
+                                if (tid < a.d) rowsh[tid] = fmax(w0 - th, 0.0);
+                                if (tid + NTH < a.d) rowsh[tid + NTH] = fmax(w1 - th, 0.0);
+                                iters += it2;
+                            }
+                        } else if (p.resets_left > 0) {
+                            code = HALT_EVENT_RESET_T;
+                            halt_bit = 0x80000000u;
+                        }
+                        __syncthreads();
+                        if (b == 0 && tid == 0) {
+                            st->nt1 = nx; st->sumT = sumT; st->proj_iters = iters;
+                            if (code != 0) { st->halt = code; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t; }
+                        }
+                        if (code == 0 && tid < CWA && j0 + tid < a.d) {
+                            const double x = rowsh[j0 + tid];
+                            Tl[t * CWA + tid] = x;
+                            st_agent(a.T + (i64)t * a.ldt + j0 + tid, x);
+                        }
+                        __syncthreads();
+                    } else if (project) {
+                        epoch += 1u;                           // the stage that is skipped still counts: every workgroup's
+                    }                                          // epoch advances alike
                 }
                 if (halt_bit == 0u) {
                     // T T[t]^T over the own slice; [k] = sum of the row.  Thread = (entry e, quarter of the 32 columns): 8 LDS
@@ -400,7 +514,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 onchip_signal(flagA + b, epoch | halt_bit);
                 RRI_STAMP(1);
             } else {
-                epoch += 1u;
+                epoch += (update_T && project) ? 2u : 1u;
             }
             if (halt_bit == 0u && !last_step) carry_pre((t + 1) % k, t, buf ^ 1);   // while the flags travel
             {
@@ -421,7 +535,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 onchip_entry_sums(a.mkP, 64, k + 1, NA, tts, wave, lane);
                 __syncthreads();
                 RRI_STAMP(3);
-                const bool row_checks = update_T || !a.skip_row_finish;
+                const bool row_checks = !project && (update_T || !a.skip_row_finish);     // with a projection: done in phase A
                 if (row_checks) {                          // _project_and_check_reset_t without a projection (nmf.py:751-769)
                     const double ps = tts[k];
                     if (b == 0 && tid == 0) {

@@ -6,7 +6,9 @@ kernels (nmf.py:437-476, 670-676, 728-734), another order of the partial sums:
     1024), ragged shapes, k = 2 and k = 22, regularisation, the c <= 0 branches with bounds;
   * against the CPU oracle (the reference's operation order): 2e-9, BASELINE's 10000 x 1000, k = 20 included;
   * reset events of both kinds through nmf(): the same events at the same steps, the same result;
-  * what the path does not cover (float64 storage, per-iteration projection of T, fixed halves, k > 22) reports not eligible
+  * the topic-model flags (T rows projected onto the simplex at every step: one more hand-over among the workers), the
+    one-hot branch of qf_min included;
+  * what the path does not cover (float64 storage, fixed halves, k > 22) reports not eligible
     and runs as before.
 """
 import os
@@ -143,8 +145,7 @@ def test_what_is_not_covered_stays_on_the_launch_per_phase_path():
     n, d, k = 900, 300, 4
     X = planted_X(n, d, k, seed=51, dtype=np.float64)
     W0, T0 = scaled_init(X, k, seed=52)
-    for dtype, params in ((np.float64, dict()), (np.float32, dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
-                          (np.float32, dict(fix_T=True)), (np.float32, dict(fix_W=True))):
+    for dtype, params in ((np.float64, dict()), (np.float32, dict(fix_T=True)), (np.float32, dict(fix_W=True))):
         with onchip(True), engine(n, d, k, dtype=dtype) as e:
             e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**params)
             assert e.onchip_info() == (False, 0)
@@ -189,3 +190,73 @@ def test_a_grid_that_cannot_synchronise_returns_an_error_instead_of_hanging(monk
     Wa, Ta, _, _ = run(X, W0, T0, 2, True)                  # the device and the library are fine afterwards
     Wb, Tb, _, _ = run(X, W0, T0, 2, False)
     assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10
+
+
+TM = dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)
+
+
+@pytest.mark.parametrize('shape', [(50, 30, 3), (1501, 333, 6), (2600, 512, 7), (10000, 1000, 20), (4096, 1024, 5)])
+def test_topic_model_flags(shape):
+    """qf_min with s = t_row_sum (optimization.py:53-59) and _project_and_check_reset_t (nmf.py:751-769) inside the persistent
+    kernel: both schedules, the oracle, rows of T on the simplex"""
+    from oracle import rri_oracle as orc
+    n, d, k = shape
+    X = planted_X(n, d, k, seed=81, dtype=np.float32)
+    X = X / X.sum(1, keepdims=True)
+    # the start the estimator makes (NNDSVDa, rows of W and T scaled to the simplex, nmf.py:840-850).  From an unscaled random
+    # start the unprojected T rows of the first sweep have sums of ~200 at 10000 x 1000: the projection then subtracts a theta
+    # a hundred times the entries it keeps, ONE half step agrees with the oracle to 1e-14 instead of 1e-16
+    # (tools/tm_parity_steps.py) and the k dependent steps amplify that to 4e-5 after a sweep -- for both schedules and both
+    # storage types alike, and invisibly to a permutation control (the reference sums the projection in sorted order)
+    from rri_nmf_amd import initialization
+    W0, T0 = initialization.initialize_nmf(np.asarray(X, dtype=np.float64), k, init='nndsvda', random_state=0)
+    T0 = T0 / T0.sum(1, keepdims=True)
+    W0 = W0 / W0.sum(1, keepdims=True)
+    Wa, Ta, oa, _ = run(X, W0, T0, 3, True, objective=True, **TM)
+    Wb, Tb, ob, _ = run(X, W0, T0, 3, False, objective=True, **TM)
+    # the two schedules: summation order only
+    assert relfro(Wa, Wb) < 1e-8 and relfro(Ta, Tb) < 1e-8, (relfro(Wa, Wb), relfro(Ta, Tb))
+    assert np.allclose(oa, ob, rtol=1e-8)
+    assert np.abs(Ta.sum(1) - 1).max() < 1e-12 and Ta.min() >= 0
+    # Against the oracle; the bound is measured: the oracle against itself on the column-permuted problem (the same mathematics,
+    # another order of the sums over columns) says what two correct implementations can differ by
+    X64, W64, T64 = np.asarray(X, dtype=np.float64), W0.astype(np.float64), T0.astype(np.float64)
+    kw = dict(max_iter=3, eps_stop=-1, project_W_each_iter=False, do_final_project_W=False, **TM)
+    ref = orc.nmf(X64, k, W_in=W64.copy(), T_in=T64.copy(), **kw)
+    perm = np.random.RandomState(0).permutation(d)
+    ctl = orc.nmf(np.ascontiguousarray(X64[:, perm]), k, W_in=W64.copy(), T_in=np.ascontiguousarray(T64[:, perm]), **kw)
+    sens = max(relfro(ctl['T'], ref['T'][:, perm]), relfro(ctl['W'], ref['W']))
+    tol = max(2e-9, 50 * sens)
+    for Tg, Wg in ((Ta, Wa), (Tb, Wb)):
+        assert relfro(Tg, ref['T']) < tol and relfro(Wg, ref['W']) < tol, (relfro(Tg, ref['T']), relfro(Wg, ref['W']), sens)
+
+
+def test_topic_model_one_hot_rows_when_the_quadratic_term_vanishes():
+    """scalar c <= 0 with s = 1: the row becomes the unit vector of the arg-max of the numerator (optimization.py:68-73)"""
+    n, d, k = 900, 300, 4
+    X = planted_X(n, d, k, seed=91, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=92)
+    flags = dict(TM, reg_t_l2=-1e9)
+    Wa, Ta, _, _ = run(X, W0, T0, 2, True, **flags)
+    Wb, Tb, _, _ = run(X, W0, T0, 2, False, **flags)
+    assert np.array_equal(Ta, Tb) and set(np.unique(Ta)) == {0.0, 1.0} and np.all(Ta.sum(1) == 1.0)
+    assert relfro(Wa, Wb) < 1e-10
+
+
+def test_topic_model_estimator_on_the_text_fixture_in_fp32_storage():
+    """NMF_TM_Estimator.fit on the reference's text fixture with fp32 storage: the persistent kernel against the
+    launch-per-phase schedule -- same topic assignments, factors to summation order"""
+    from rri_nmf_amd import sklearn_interface as si
+    from conftest import load_golden
+    g = load_golden('g1_tm_estimator')
+    X = np.asarray(g['X'], dtype=np.float64)
+    n, d = X.shape
+    out = []
+    for on in (True, False):
+        with onchip(on):
+            E = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=10, nmf_kwargs={'eps_stop': -1, 'dtype': np.float32}).fit(X)
+            out.append((E.W.copy(), E.T.copy()))
+    (Wa, Ta), (Wb, Tb) = out
+    assert relfro(Wa, Wb) < 1e-9 and relfro(Ta, Tb) < 1e-9
+    assert np.array_equal(np.argmax(Wa, 1), np.argmax(Wb, 1))
+    assert np.array_equal(np.argmax(Wa, 1), g['argmax_s10'])        # the reference's own assignments after 10 sweeps (float64 run)

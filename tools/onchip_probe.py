@@ -6,14 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rri_nmf_amd.engine import RRIEngine
 from rri_nmf_amd.synthetic import planted_X, scaled_init
 
-n, d, k, sweeps = [int(v) for v in (sys.argv[1:5] + ['10000', '1000', '20', '50'][len(sys.argv) - 1:])]
+n, d, k, sweeps = [int(v) for v in (sys.argv[1:5] + ['10000', '1000', '20', '50'][len(sys.argv[1:5]):])]
+flags = dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0) if 'tm' in sys.argv[5:] else {}      # 'tm': the topic-model flag set
 X = planted_X(n, d, k, seed=1, dtype=np.float32)
 W0, T0 = scaled_init(X, k, seed=2)
 res = {}
 for on in ('1', '0'):
     os.environ['RRI_ONCHIP'] = on
     with RRIEngine(n, d, k, dtype=np.float32) as e:
-        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
         print('RRI_ONCHIP=%s eligible/launches %r' % (on, e.onchip_info()), flush=True)
         e.sweep(2)
         e.synchronize()

@@ -275,7 +275,7 @@ rri_status rri_objective_parts(rri_ctx* ctx, double out[3]);
 rri_status rri_timing_enable(rri_ctx* ctx, int32_t on);
 rri_status rri_timing_read(rri_ctx* ctx, int32_t kernel_id, int64_t* launches, double* total_ms);
 rri_status rri_synchronize(rri_ctx* ctx);
-/* Launch-bound sizes: when X (fp32) fits the registers of the chip -- up to about 20000 x 1024 -- and the configuration
+/* Launch-bound sizes: when X fits the registers of the chip -- up to about 10000 x 1024 in fp32, half the rows in float64 -- and the configuration
  * is the unweighted one with both halves free (plain, or the topic-model flags with T rows projected at every step), k in
  * 2..22, one device, rri_sweep / rri_resume run as ONE persistent launch with X resident on chip and two (topic model:
  * three) hand-overs between workgroups per topic step (rri_onchip_kernels.hpp) instead of three or four launches per topic

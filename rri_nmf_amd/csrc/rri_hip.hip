@@ -1369,32 +1369,32 @@ bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     g->rpw = (g->rows_wg + g->RG - 1) / g->RG;
     g->NA = (int)((c->LD + ONCHIP_CWA - 1) / ONCHIP_CWA);      // workgroups that also own a column slice of T
     g->kS = c->k | 1;                                  // odd row stride of the LDS copy of W: no bank conflicts down a column
-    if (g->rpw > ONCHIP_MAX_RPW || g->NA > 64 || g->NA > g->G || (i64)g->rows_wg * g->kS > 6144) return false;
+    if (g->rpw > (c->dtype == RRI_F32 ? ONCHIP_MAX_RPW : ONCHIP_MAX_RPW / 2) || g->NA > 64 || g->NA > g->G || (i64)g->rows_wg * g->kS > 6144) return false;
     const size_t doubles = (size_t)g->rows_wg * g->kS + (size_t)c->k * ONCHIP_CWA + (c->k + 2) + (c->k + 1) +
                            (size_t)ONCHIP_PG * ONCHIP_CWA + (size_t)g->CG * g->rows_wg + g->rows_wg +
                            (size_t)ONCHIP_WAVES * 256 + (size_t)ONCHIP_WAVES * 8 * 72 + 1024 + 40;
     g->shmem = doubles * sizeof(double);
     return g->shmem <= 150 * 1024;
 }
-// what the persistent kernel covers: the plain flavour with fp32 storage, both halves free (with or without the per-step
+// what the persistent kernel covers: the unweighted flavour, either storage type, both halves free (with or without the per-step
 // simplex projection of T), 2 <= k <= ONCHIP_MAX_K, on one device
 bool onchip_ok(const rri_ctx* c) {
     OnchipGeom g;
-    return g_onchip && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->dtype == RRI_F32 && c->k >= 2 &&
-           c->k <= ONCHIP_MAX_K && !c->prm.fix_W && !c->prm.fix_T && c->ldx % 4 == 0 && ((uintptr_t)c->X) % 16 == 0 &&
+    return g_onchip && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
+           c->k <= ONCHIP_MAX_K && !c->prm.fix_W && !c->prm.fix_T && c->ldx % c->VN == 0 && ((uintptr_t)c->X) % 16 == 0 &&
            onchip_geometry(c, &g);
 }
-template <int RPW, bool DBG = false, bool PROJ = false>
+template <typename SX, int RPW, bool DBG = false, bool PROJ = false>
 hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
     static bool attr_set[64] = {};
     const int dv = c->device & 63;
     if (!attr_set[dv]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_onchip_sweeps<RPW, DBG, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_onchip_sweeps<SX, RPW, DBG, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: hipFuncSetAttribute\n"); return e; }
         attr_set[dv] = true;
     }
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onchip_sweeps<RPW, DBG, PROJ>, ONCHIP_THREADS, g.shmem);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onchip_sweeps<SX, RPW, DBG, PROJ>, ONCHIP_THREADS, g.shmem);
     if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: occupancy %d per CU (%s), %d CUs\n", per_cu, hipGetErrorString(e), c->n_cu);
     if (e != hipSuccess) return e;
     if ((i64)per_cu * c->n_cu < g.G) return hipErrorCooperativeLaunchTooLarge;     // the hand-overs need every workgroup resident
@@ -1408,7 +1408,7 @@ hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
     const int dv2 = c->device & 63;
     if (!last[dv2] && hipEventCreateWithFlags(&last[dv2], hipEventDisableTiming) != hipSuccess) last[dv2] = nullptr;
     if (last[dv2]) (void)hipStreamWaitEvent(c->stream, last[dv2], 0);
-    hipLaunchKernelGGL((k_onchip_sweeps<RPW, DBG, PROJ>), dim3(g.G), dim3(ONCHIP_THREADS), g.shmem, c->stream, a);
+    hipLaunchKernelGGL((k_onchip_sweeps<SX, RPW, DBG, PROJ>), dim3(g.G), dim3(ONCHIP_THREADS), g.shmem, c->stream, a);
     const hipError_t le = hipGetLastError();
     if (le == hipSuccess && last[dv2]) (void)hipEventRecord(last[dv2], c->stream);
     return le;
@@ -1430,7 +1430,7 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     if (!c->mkG || !c->mkP || !c->mkbar) return false;
     (void)hipMemsetAsync(c->mkbar, 0, (size_t)(128 + g.G) * sizeof(unsigned), c->stream);
     OnchipArgs a{};
-    a.X = (const float*)c->X; a.ldx = c->ldx; a.n = (int)c->n; a.d = (int)c->d; a.LD = (int)c->LD; a.k = k;
+    a.X = c->X; a.ldx = c->ldx; a.n = (int)c->n; a.d = (int)c->d; a.LD = (int)c->LD; a.k = k;
     a.Wt = c->W; a.ldw = c->ldw; a.T = c->T; a.ldt = c->LD;
     a.mkZ = c->mkZ; a.mkG = c->mkG; a.mkP = c->mkP; a.xraw = c->xraw; a.xyp = c->XYpart; a.xy_stride = c->xy_stride; a.bar = c->mkbar;
     a.G = g.G; a.NA = g.NA; a.rows_wg = g.rows_wg; a.CG = g.CG; a.RG = g.RG; a.kS = g.kS;
@@ -1463,10 +1463,13 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         const bool timed = c->timing > 0 && c->timed[0].size() < 400000;
         if (timed) { tl.a = get_event(c); tl.b = get_event(c); (void)hipEventRecord(tl.a, c->stream); }
         const bool proj = !LK::light(c);          // project_T_each_iter with a t_row_sum: the topic-model instantiation
-        if (proj) e = g.rpw <= 8 ? onchip_launch<8, false, true>(c, g, a) : onchip_launch<ONCHIP_MAX_RPW, false, true>(c, g, a);
-        else if (a.dbg) e = g.rpw <= 8 ? onchip_launch<8, true>(c, g, a) : onchip_launch<ONCHIP_MAX_RPW, true>(c, g, a);
-        else if (g.rpw <= 8) e = onchip_launch<8>(c, g, a);
-        else e = onchip_launch<ONCHIP_MAX_RPW>(c, g, a);
+        if (c->dtype == RRI_F64) {                // 8 registers per row and lane: half the rows of the fp32 instantiations
+            if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, true>(c, g, a);
+            else e = g.rpw <= 4 ? onchip_launch<double, 4>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2>(c, g, a);
+        } else if (proj) e = g.rpw <= 8 ? onchip_launch<float, 8, false, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, true>(c, g, a);
+        else if (a.dbg) e = g.rpw <= 8 ? onchip_launch<float, 8, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, true>(c, g, a);
+        else if (g.rpw <= 8) e = onchip_launch<float, 8>(c, g, a);
+        else e = onchip_launch<float, ONCHIP_MAX_RPW>(c, g, a);
         if (timed) { (void)hipEventRecord(tl.b, c->stream); c->timed[0].push_back(tl); }
     }
     if (e != hipSuccess) {

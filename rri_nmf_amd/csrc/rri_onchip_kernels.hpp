@@ -52,7 +52,7 @@ constexpr int ONCHIP_CWA = 32;          // columns of T per worker
 constexpr int ONCHIP_PG = ONCHIP_THREADS / ONCHIP_CWA;   // groups of workgroup partials in the column-sum reduction
 
 struct OnchipArgs {
-    const float* X; i64 ldx; int n, d, LD, k;
+    const void* X; i64 ldx; int n, d, LD, k;      // X in the handle's storage type (the kernel is instantiated per type)
     double* Wt; i64 ldw; double* T; i64 ldt;
     double* mkZ;                   // [2][G][LD]   column-sum partials of the carried topic (two buffers: by the parity of the step that reads)
     double* mkG;                   // [2][k+2][G]  Gram-row partials | ||w||^2 | column sum of the last update, entry-major
@@ -185,7 +185,7 @@ __device__ __forceinline__ double onchip_simplex_theta(double v0, double v1, dou
 // tools/onchip_probe.py): 0 phase A loads, 1 phase A rest + signal, 2 wait for the workers, 3 phase B loads, 4 row dots,
 // 5 W update, 6 carry, 7 hand-over to the workers
 // PROJ: the instantiation for the topic-model flags (the projection stage costs the plain one registers it does not have)
-template <int RPW, bool DBG = false, bool PROJ = false>
+template <typename SX, int RPW, bool DBG = false, bool PROJ = false>
 __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) {
     constexpr int NTH = ONCHIP_THREADS, NWV = ONCHIP_WAVES, CWA = ONCHIP_CWA, PG = ONCHIP_PG;
     DevState* st = a.st;
@@ -230,17 +230,30 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                                                             // the host picks the instantiation from project_T && has_t_row_sum
 
     // ---- residents: X rows -> registers, W rows and (workers) the T slice -> LDS ------------------------------------
-    float xr[RPW][4];
+    SX xr[RPW][4];       // float: 4 registers per row, RPW <= 20; double: 8 per row, RPW <= 10
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int lr = rg + RG * r;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lr < rows_here && col0 < a.LD) v = *reinterpret_cast<const f32x4*>(a.X + (i64)(row0 + lr) * a.ldx + col0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xr[r][c] = v[c];
+        for (int c = 0; c < 4; ++c) xr[r][c] = SX(0);
+        if (lr < rows_here && col0 < a.LD) {
+            const SX* src = static_cast<const SX*>(a.X) + (i64)(row0 + lr) * a.ldx + col0;
+            if constexpr (sizeof(SX) == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xr[r][c] = v[c];
+            } else {                                      // LD is a multiple of 2 only: the second pair may lie past the row
+                const f64x2 v0 = *reinterpret_cast<const f64x2*>(src);
+                xr[r][0] = v0[0]; xr[r][1] = v0[1];
+                if (col0 + 2 < a.LD) {
+                    const f64x2 v1 = *reinterpret_cast<const f64x2*>(src + 2);
+                    xr[r][2] = v1[0]; xr[r][3] = v1[1];
+                }
+            }
+        }
     }
-    // X stays fp32 in the registers and is widened where it is used: the compiler must not hoist the conversions out of
-    // the topic loop (it would keep a float64 copy of every element: three times the registers)
+    // fp32 X stays fp32 in the registers and is widened where it is used: the compiler must not hoist the conversions out
+    // of the topic loop (it would keep a float64 copy of every element: three times the registers)
     auto keep_fp32 = [&]() {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(xr[r][0]), "+v"(xr[r][1]), "+v"(xr[r][2]), "+v"(xr[r][3]));
@@ -528,10 +541,9 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
             // ---------------- phase B: row checks, W column t on the own rows, carry of topic t + 1 ---------------
             {
                 double tv[4] = {0.0, 0.0, 0.0, 0.0};
-                if (col0 < a.LD) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) tv[c] = ld_agent(a.T + (unsigned)(t * (int)a.ldt + col0 + c));
-                }
+                for (int c = 0; c < 4; ++c)
+                    if (col0 + c < a.LD) tv[c] = ld_agent(a.T + (unsigned)(t * (int)a.ldt + col0 + c));
                 onchip_entry_sums(a.mkP, 64, k + 1, NA, tts, wave, lane);
                 __syncthreads();
                 RRI_STAMP(3);

@@ -411,6 +411,7 @@ def test_captured_sweeps_equal_eager_sweeps(weighted, monkeypatch):
     W0, T0 = scaled_init(X, k, seed=1)
     M = (np.random.RandomState(3).rand(n, d) < 0.3).astype(np.float64)
     out = {}
+    monkeypatch.setenv('RRI_ONCHIP', '0')               # captured sweeps are the launch-per-phase schedule's
     for mode in ('0', '2'):
         monkeypatch.setenv('RRI_GRAPH', mode)
         for flags in (dict(), dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0), dict(t_row_sum=1.0, reg_w_l1=1e6, n_resets=1000)):

@@ -8,7 +8,9 @@ kernels (nmf.py:437-476, 670-676, 728-734), another order of the partial sums:
   * reset events of both kinds through nmf(): the same events at the same steps, the same result;
   * the topic-model flags (T rows projected onto the simplex at every step: one more hand-over among the workers), the
     one-hot branch of qf_min included;
-  * what the path does not cover (float64 storage, fixed halves, k > 22) reports not eligible
+  * float64 storage (half the rows per workgroup), the reference's vectors through it (the goldens of tests/golden run in
+    float64: test_hip_parity.py / test_nmf_gpu.py take this path wherever the configuration allows);
+  * what the path does not cover (fixed halves, k > 22, too many rows for the registers) reports not eligible
     and runs as before.
 """
 import os
@@ -44,10 +46,10 @@ class onchip(object):
             os.environ['RRI_ONCHIP'] = self.old
 
 
-def run(X, W0, T0, sweeps, on, objective=False, **params):
+def run(X, W0, T0, sweeps, on, objective=False, dtype=np.float32, **params):
     n, d = X.shape
     k = W0.shape[1]
-    with onchip(on), engine(n, d, k, dtype=np.float32) as e:
+    with onchip(on), engine(n, d, k, dtype=dtype) as e:
         e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**params)
         eligible, before = e.onchip_info()
         assert eligible == bool(on), (eligible, on)
@@ -145,7 +147,7 @@ def test_what_is_not_covered_stays_on_the_launch_per_phase_path():
     n, d, k = 900, 300, 4
     X = planted_X(n, d, k, seed=51, dtype=np.float64)
     W0, T0 = scaled_init(X, k, seed=52)
-    for dtype, params in ((np.float64, dict()), (np.float32, dict(fix_T=True)), (np.float32, dict(fix_W=True))):
+    for dtype, params in ((np.float32, dict(fix_T=True)), (np.float64, dict(fix_W=True))):
         with onchip(True), engine(n, d, k, dtype=dtype) as e:
             e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**params)
             assert e.onchip_info() == (False, 0)
@@ -260,3 +262,29 @@ def test_topic_model_estimator_on_the_text_fixture_in_fp32_storage():
     assert relfro(Wa, Wb) < 1e-9 and relfro(Ta, Tb) < 1e-9
     assert np.array_equal(np.argmax(Wa, 1), np.argmax(Wb, 1))
     assert np.array_equal(np.argmax(Wa, 1), g['argmax_s10'])        # the reference's own assignments after 10 sweeps (float64 run)
+
+
+@pytest.mark.parametrize('shape', [(50, 30, 3), (1501, 333, 6), (2501, 1000, 12), (5000, 1022, 20), (2600, 510, 7)])
+@pytest.mark.parametrize('flags', [dict(), TM])
+def test_float64_storage(shape, flags):
+    """8 registers per row and lane; LD is a multiple of 2 only (the second pair of a lane's four columns may lie past the row)"""
+    from oracle import rri_oracle as orc
+    n, d, k = shape
+    X = planted_X(n, d, k, seed=101, dtype=np.float64)
+    if flags:
+        from rri_nmf_amd import initialization
+        X = X / X.sum(1, keepdims=True)
+        W0, T0 = initialization.initialize_nmf(X, k, init='nndsvda', random_state=0)
+        T0, W0 = T0 / T0.sum(1, keepdims=True), W0 / W0.sum(1, keepdims=True)
+    else:
+        W0, T0 = scaled_init(X, k, seed=102)
+    Wa, Ta, oa, _ = run(X, W0, T0, 3, True, objective=True, dtype=np.float64, **flags)
+    Wb, Tb, ob, _ = run(X, W0, T0, 3, False, objective=True, dtype=np.float64, **flags)
+    assert relfro(Wa, Wb) < 1e-8 and relfro(Ta, Tb) < 1e-8, (relfro(Wa, Wb), relfro(Ta, Tb))
+    assert np.allclose(oa, ob, rtol=1e-8)
+    kw = dict(max_iter=3, eps_stop=-1, project_W_each_iter=False, do_final_project_W=False, **flags)
+    ref = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), **kw)
+    perm = np.random.RandomState(0).permutation(d)
+    ctl = orc.nmf(np.ascontiguousarray(X[:, perm]), k, W_in=W0.copy(), T_in=np.ascontiguousarray(T0[:, perm]), **kw)
+    tol = max(2e-9, 50 * max(relfro(ctl['T'], ref['T'][:, perm]), relfro(ctl['W'], ref['W'])))
+    assert relfro(Ta, ref['T']) < tol and relfro(Wa, ref['W']) < tol, (relfro(Ta, ref['T']), relfro(Wa, ref['W']), tol)

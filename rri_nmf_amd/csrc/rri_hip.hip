@@ -1478,6 +1478,13 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         return false;
     }
     c->onchip_launches += 1;
+    if (const char* path = getenv("RRI_ONCHIP_LOG")) {      // tests: which configurations took this path (one line per launch)
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "%lld %lld %d %s %s sweeps %d..%d\n", (long long)c->n, (long long)c->d, k, c->dtype == RRI_F32 ? "f32" : "f64",
+                    LK::light(c) ? "plain" : "simplex", cur.sweep, c->run_total);
+            fclose(f);
+        }
+    }
     // what the launch-per-phase schedule would find after these sweeps: no carried sums, nothing pending (the kernel
     // ran the last column check itself); the objective's cross terms are complete when the last sweep ran from topic 0
     const bool whole_last = c->run_total - 1 > cur.sweep || (cur.topic == 0 && cur.phase == 0);

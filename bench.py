@@ -589,6 +589,37 @@ def main():
                     'vs_default_schedule_after_%d_sweeps' % (args.warmup + args.steps): {'relfro_W': relfro(Wr, Wd), 'relfro_T': relfro(Tr, Td)}}
             except Exception as e:  # noqa: BLE001
                 out['rank1_update']['schedule'] = {'error': str(e)}
+        if onchip:
+            # the same problem, start and sweeps through the launch-per-phase schedule (RRI_ONCHIP=0, read by rri_create):
+            # three launches per topic step with X re-read from the caches
+            try:
+                saved = os.environ.get('RRI_ONCHIP')
+                os.environ['RRI_ONCHIP'] = '0'
+                try:
+                    e4 = RRIEngine(n_local, d, k, dtype=sdt, device=local_rank)
+                finally:
+                    if saved is None:
+                        os.environ.pop('RRI_ONCHIP', None)
+                    else:
+                        os.environ['RRI_ONCHIP'] = saved
+                with e4:
+                    e4.bind_X_device(X.data_ptr(), X.stride(0))
+                    e4.set_W(W0), e4.set_T(T0), e4.set_params()
+                    e4.sweep(max(args.warmup, 1))
+                    e4.synchronize()
+                    t4 = time.perf_counter()
+                    e4.sweep(args.steps)
+                    e4.synchronize()
+                    dt4 = time.perf_counter() - t4
+                    W4, T4 = e4.get_W(), e4.get_T()
+                Wd, Td = eng.get_W(), eng.get_T()
+                out['launch_per_phase_schedule'] = {
+                    'what': 'RRI_ONCHIP=0: k_trow_small + k_pass + k_wcol per topic step, no HIP-event timing',
+                    'sweeps_per_s': args.steps / dt4, 'us_per_topic_step': 1e6 * dt4 / args.steps / k,
+                    'persistent_launch_us_per_topic_step': 1e6 * elapsed / args.steps / k,
+                    'vs_persistent_launch_after_%d_sweeps' % (max(args.warmup, 1) + args.steps): {'relfro_W': relfro(Wd, W4), 'relfro_T': relfro(Td, T4)}}
+            except Exception as e:  # noqa: BLE001
+                out['launch_per_phase_schedule'] = {'error': str(e)}
         if not args.no_cpu_baseline:
             full = args.config in ('c2', 'c3', 'mid')
             rows = args.cpu_rows or (n_local if full else min(100000, n_local))

@@ -1356,9 +1356,6 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) 
 
 // ---- register-resident persistent sweeps (rri_onchip_kernels.hpp) ---------------------------------------------
 struct OnchipGeom { int CG, RG, rows_wg, rpw, NA, kS, G; size_t shmem; };
-constexpr int ONCHIP_MAX_K = 22;      // k + 2 Gram entries = 8 waves x 3 in flight: one round trip in phase A.  Beyond that the
-                                      // per-topic cost of the kernel grows faster than that of the launch-per-phase schedule
-                                      // (5000 x 1000: -3 % at k = 24 and 32, -15 % at k = 64; profiles/r02_onchip_sizes.log)
 constexpr int ONCHIP_MAX_RPW = 20;    // rows per wave held in registers (float4 each): 32 spills at 256 VGPRs
 bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     if (c->LD > 1024 || c->n_cu < 1) return false;

@@ -48,6 +48,9 @@ namespace rri {
 
 enum { HALT_ERR_GRID_SYNC = -8 };
 constexpr int ONCHIP_THREADS = 512, ONCHIP_WAVES = ONCHIP_THREADS / 64;
+constexpr int ONCHIP_MAX_K = 22;      // k + 2 Gram entries = 8 waves x 3 in flight: one round trip in phase A.  Beyond that the
+                                      // per-topic cost of the kernel grows faster than that of the launch-per-phase schedule
+                                      // (5000 x 1000: -3 % at k = 24 and 32, -15 % at k = 64; profiles/r02_onchip_sizes.log)
 constexpr int ONCHIP_CWA = 32;          // columns of T per worker
 constexpr int ONCHIP_PG = ONCHIP_THREADS / ONCHIP_CWA;   // groups of workgroup partials in the column-sum reduction
 
@@ -401,33 +404,38 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         }
                     }
                     if (code != 0) halt_bit = 0x80000000u;     // every worker takes the same verdict from the same sums
-                    else if (tid < CWA && j0 + tid < a.d) {
-                        double z = 0.0;
-#pragma unroll 1
-                        for (int q = 0; q < PG; ++q) z += zred[q * CWA + tid];
-                        double acc = 0.0;
-#pragma unroll 1
-                        for (int l0 = 0; l0 < k; l0 += 8) {        // 8 LDS reads in flight; the terms still added in topic order
-                            double gv[8], tvv[8];
+                    else if (tid < 8 * CWA) {
+                        // the closed form for the own columns: 8 lanes per column share the PG partial column sums and the
+                        // k-term product with the Gram row (all their LDS reads in flight at once), three shuffles add the parts
+                        const int jc = tid >> 3, sub = tid & 7;
+                        constexpr int TERMS = (ONCHIP_MAX_K + 7) / 8;
+                        double zpart = 0.0, acc = 0.0;
+                        double gv[TERMS], tvv[TERMS], zq[PG / 8];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int l = l0 + q;
-                                gv[q] = (l < k && l != t) ? gsh[l] : 0.0;
-                                tvv[q] = (l < k) ? Tl[l * CWA + tid] : 0.0;
-                            }
+                        for (int q = 0; q < PG / 8; ++q) zq[q] = zred[(sub + 8 * q) * CWA + jc];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q)
-                                if (l0 + q < k && l0 + q != t) acc = fma(gv[q], tvv[q], acc);
+                        for (int q = 0; q < TERMS; ++q) {
+                            const int l = sub + 8 * q;
+                            gv[q] = (l < k && l != t) ? gsh[l] : 0.0;
+                            tvv[q] = (l < k) ? Tl[l * CWA + jc] : 0.0;
                         }
-                        const double numer = (z - acc) - p.reg_t_l1;
-                        double x;
-                        if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
-                        else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
-                        else x = numer;                            // mode 2: the arg-max of the numerator takes it all
-                        if (project) st_agent(a.xraw + (unsigned)(j0 + tid), x);
-                        else {
-                            Tl[t * CWA + tid] = x;
-                            st_agent(a.T + (i64)t * a.ldt + j0 + tid, x);
+#pragma unroll
+                        for (int q = 0; q < PG / 8; ++q) zpart += zq[q];
+#pragma unroll
+                        for (int q = 0; q < TERMS; ++q) acc = fma(gv[q], tvv[q], acc);
+                        zpart += __shfl_xor(zpart, 1, 8); zpart += __shfl_xor(zpart, 2, 8); zpart += __shfl_xor(zpart, 4, 8);
+                        acc += __shfl_xor(acc, 1, 8); acc += __shfl_xor(acc, 2, 8); acc += __shfl_xor(acc, 4, 8);
+                        if (sub == 0 && j0 + jc < a.d) {
+                            const double numer = (zpart - acc) - p.reg_t_l1;
+                            double x;
+                            if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
+                            else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
+                            else x = numer;                        // mode 2: the arg-max of the numerator takes it all
+                            if (project) st_agent(a.xraw + (unsigned)(j0 + jc), x);
+                            else {
+                                Tl[t * CWA + jc] = x;
+                                st_agent(a.T + (i64)t * a.ldt + j0 + jc, x);
+                            }
                         }
                     }
                     __syncthreads();
@@ -592,31 +600,35 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 }
                 __syncthreads();
                 RRI_STAMP(4);
-                if (tid < rows_here) {
-                    double y = 0.0;
-#pragma unroll 1
-                    for (int q = 0; q < CG; ++q) y += ysh[(size_t)q * a.rows_wg + tid];
-                    double dot = 0.0;
-#pragma unroll 1
-                    for (int l0 = 0; l0 < k; l0 += 8) {            // 8 LDS reads in flight; the terms still added in topic order
-                        double wv[8], sv[8];
+                // W column t for the own rows: 8 lanes per row share the k-term dot (lane sub takes the topics sub, sub + 8,
+                // sub + 16: all their LDS reads in flight at once) and the CG row-dot partials; three shuffles add the parts
+                for (int r0 = 0; r0 < rows_here; r0 += NTH / 8) {
+                    const int i = r0 + (tid >> 3), sub = tid & 7;
+                    constexpr int TERMS = (ONCHIP_MAX_K + 7) / 8;
+                    double part = 0.0, y = 0.0;
+                    if (i < rows_here) {
+                        double wv[TERMS], sv[TERMS];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int l = l0 + q;
-                            wv[q] = (l < k) ? Wl[(size_t)tid * kS + l] : 0.0;
+                        for (int q = 0; q < TERMS; ++q) {
+                            const int l = sub + 8 * q;
+                            wv[q] = (l < k) ? Wl[(size_t)i * kS + l] : 0.0;
                             sv[q] = (l < k && l != t) ? tts[l] : 0.0;
                         }
+                        if (sub < CG) y = ysh[(size_t)sub * a.rows_wg + i];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (l0 + q < k && l0 + q != t) dot = fma(wv[q], sv[q], dot);
+                        for (int q = 0; q < TERMS; ++q) part = fma(wv[q], sv[q], part);
                     }
-                    const double numer = (y - dot) - p.reg_w_l1;
-                    double wnew;
-                    if (wmode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
-                    else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
-                    Wl[(size_t)tid * kS + t] = wnew;
-                    a.Wt[(i64)t * a.ldw + row0 + tid] = wnew;
-                    xyl[tid] = wnew * y;
+                    part += __shfl_xor(part, 1, 8); part += __shfl_xor(part, 2, 8); part += __shfl_xor(part, 4, 8);
+                    y += __shfl_xor(y, 1, 8); y += __shfl_xor(y, 2, 8);          // CG <= 4 partials, in lanes 0 .. 3
+                    if (i < rows_here && sub == 0) {
+                        const double numer = (y - part) - p.reg_w_l1;
+                        double wnew;
+                        if (wmode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
+                        else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
+                        Wl[(size_t)i * kS + t] = wnew;
+                        a.Wt[(i64)t * a.ldw + row0 + i] = wnew;
+                        xyl[i] = wnew * y;
+                    }
                 }
                 __syncthreads();
                 if (wave == 0) {                           // <w_t, X t_t> over the own rows: the objective's cross term

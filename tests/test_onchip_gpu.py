@@ -288,3 +288,16 @@ def test_float64_storage(shape, flags):
     ctl = orc.nmf(np.ascontiguousarray(X[:, perm]), k, W_in=W0.copy(), T_in=np.ascontiguousarray(T0[:, perm]), **kw)
     tol = max(2e-9, 50 * max(relfro(ctl['T'], ref['T'][:, perm]), relfro(ctl['W'], ref['W'])))
     assert relfro(Ta, ref['T']) < tol and relfro(Wa, ref['W']) < tol, (relfro(Ta, ref['T']), relfro(Wa, ref['W']), tol)
+
+
+@pytest.mark.parametrize('flags', [dict(), TM])
+def test_same_bits_run_to_run(flags):
+    """every sum of the persistent kernel has a fixed order (no atomics, the flags only order the phases): two runs of the
+    same problem give the same bits, whatever the order in which workgroups arrive at the hand-overs"""
+    n, d, k = 6000, 1000, 12
+    X = planted_X(n, d, k, seed=111, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=112)
+    T0 = T0 / T0.sum(1, keepdims=True)
+    runs = [run(X, W0, T0, 7, True, **flags) for _ in range(3)]
+    for Wr, Tr, _, _ in runs[1:]:
+        assert np.array_equal(Wr, runs[0][0]) and np.array_equal(Tr, runs[0][1])

@@ -209,7 +209,8 @@ rri_status rri_scale_X(rri_ctx* ctx, const double* col_scale, int32_t normalize_
  *      weighted flavour) is all-reduced by RCCL over xGMI on the handle's stream between two kernels: a sweep is ONE
  *      call with no host work per topic.  Every decision (reset events, the assert of nmf.py:476, unbounded cases)
  *      is taken from all-reduced or replicated values, so all ranks return the same status.
- *      All flavours and flags of rri_sweep (fixed halves, k = 1, weighted, pattern-only) except RRI_UNWEIGHTED_RESIDUAL. */
+ *      All flavours and flags of rri_sweep: fixed halves, k = 1, weighted dense and pattern-only, and the explicit-residual
+ *      schedule (RRI_UNWEIGHTED_RESIDUAL: every rank keeps its rows of R; the sums it sends are the same message). */
 /* rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks by any channel the host program has */
 rri_status rri_comm_unique_id(uint8_t* id_out /* RRI_COMM_ID_BYTES */);
 /* RCCL communicator of `world` ranks; this process is `rank` and drives HIP device `device`.  Collective. */
@@ -283,6 +284,11 @@ rri_status rri_synchronize(rri_ctx* ctx);
  * rri_sweep take that path; *launches: how many it has taken on this handle.  RRI_ONCHIP=0 (environment, read by
  * rri_create) switches it off.  Either pointer may be NULL. */
 rri_status rri_onchip_info(rri_ctx* ctx, int32_t* eligible, int64_t* launches);
+/* The hand-overs of that launch poll a bounded number of times.  When its workgroups cannot all run at once (a device shared
+ * with another process, CUs masked away) the launch gives up, and the call does what the reference's sweep does under any
+ * scheduling (nmf.py:415-476): it completes -- W and T are put back to what they were before the launch and the same steps
+ * run on the launch-per-phase schedule, which the handle then keeps.  *fallbacks: how often that happened on this handle. */
+rri_status rri_onchip_fallbacks(rri_ctx* ctx, int64_t* fallbacks);
 /* Stand-alone kernels for roofline measurement (bench.py): R <- R - a b^T fused with the
  * next residual products, on a scratch copy of X, with the handle's own W[:,0], T[0,:] as factors. */
 rri_status rri_bench_rank1_update(rri_ctx* ctx, int32_t reps, double* avg_ms);

@@ -241,6 +241,14 @@ struct rri_ctx {
     double *mkZ = nullptr, *mkG = nullptr, *mkP = nullptr;
     unsigned* mkbar = nullptr;
     long onchip_launches = 0;
+    // a persistent launch whose workgroups could not synchronise (HALT_ERR_GRID_SYNC: the device was shared, not every
+    // workgroup resident in time) is undone and its range of steps run on the launch-per-phase schedule instead:
+    // W, T as they were before the launch, the host flags the launch-per-phase schedule would have started from
+    double *Wsafe = nullptr, *Tsafe = nullptr;
+    bool onchip_in_flight = false;      // the sequence just enqueued was a persistent launch (run_and_collect reads it)
+    bool onchip_off = false;            // after a fallback the handle stays on the launch-per-phase schedule
+    bool onchip_saved_skip = false;
+    long onchip_fallbacks = 0;
 
     int timing = 0;            // 0 off, N > 0: time every N-th launch of each kernel id
     long timing_seq[4] = {0, 0, 0, 0};
@@ -1377,16 +1385,43 @@ bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
 // simplex projection of T), 2 <= k <= ONCHIP_MAX_K, on one device
 bool onchip_ok(const rri_ctx* c) {
     OnchipGeom g;
-    return g_onchip && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
+    return g_onchip && !c->onchip_off && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
            c->k <= ONCHIP_MAX_K && !c->prm.fix_W && !c->prm.fix_T && c->ldx % c->VN == 0 && ((uintptr_t)c->X) % 16 == 0 &&
            onchip_geometry(c, &g);
+}
+// Two persistent grids on one device (two handles on two streams) must not each hold a part of the CUs while waiting for
+// the rest: inside a process EVERY persistent launch -- whatever its instantiation -- waits for the one before it on the same
+// device (one mutex, one event per device, both at file scope: round 2 kept them inside the launch template, one set per
+// instantiation, so an fp32 and a float64 handle were not ordered against each other).  Across processes nothing orders
+// two grids; there the bounded polls end the wait and the call falls back (run_and_collect).
+// hipLaunchCooperativeKernel is NOT used: it gives no stronger residency than a plain launch of a grid checked against the
+// occupancy query (same admission, same queue), costs 15-19 us per launch, and a process that has used it dies in the HIP
+// runtime's own exit handler under rocprofv3 ("the exit-time fault"; RRI_ONCHIP_COOP=1 keeps it reachable for
+// tools/exit_probe).
+std::mutex g_onchip_mu;
+hipEvent_t g_onchip_last[64] = {};
+int g_onchip_coop = 0;   // RRI_ONCHIP_COOP=1 (diagnostics): hipLaunchCooperativeKernel instead of the plain launch
+hipError_t onchip_ordered_launch(rri_ctx* c, const void* fn, int grid, size_t shmem, const OnchipArgs& a) {
+    std::lock_guard<std::mutex> lock(g_onchip_mu);
+    const int dv = c->device & 63;
+    if (!g_onchip_last[dv] && hipEventCreateWithFlags(&g_onchip_last[dv], hipEventDisableTiming) != hipSuccess) g_onchip_last[dv] = nullptr;
+    if (g_onchip_last[dv]) (void)hipStreamWaitEvent(c->stream, g_onchip_last[dv], 0);
+    OnchipArgs copy = a;
+    void* args[] = {(void*)&copy};
+    hipError_t le;
+    if (g_onchip_coop) le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(ONCHIP_THREADS), args, (unsigned)shmem, c->stream);
+    else le = hipLaunchKernel(fn, dim3(grid), dim3(ONCHIP_THREADS), args, shmem, c->stream);
+    if (le == hipSuccess) le = hipGetLastError();
+    if (le == hipSuccess && g_onchip_last[dv]) (void)hipEventRecord(g_onchip_last[dv], c->stream);
+    return le;
 }
 template <typename SX, int RPW, bool DBG = false, bool PROJ = false>
 hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
     static bool attr_set[64] = {};
     const int dv = c->device & 63;
+    const void* fn = (const void*)k_onchip_sweeps<SX, RPW, DBG, PROJ>;
     if (!attr_set[dv]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_onchip_sweeps<SX, RPW, DBG, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: hipFuncSetAttribute\n"); return e; }
         attr_set[dv] = true;
     }
@@ -1395,20 +1430,7 @@ hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
     if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: occupancy %d per CU (%s), %d CUs\n", per_cu, hipGetErrorString(e), c->n_cu);
     if (e != hipSuccess) return e;
     if ((i64)per_cu * c->n_cu < g.G) return hipErrorCooperativeLaunchTooLarge;     // the hand-overs need every workgroup resident
-    // Two such grids on one device (two handles on two streams) must not each hold a part of the CUs while waiting for the
-    // rest: inside a process every persistent launch waits for the one before it.  (hipLaunchCooperativeKernel gives the
-    // same guarantee from the runtime and worked, but a process that had used it crashed in its exit handlers under
-    // rocprofv3 on ROCm 7.2 -- after the tool had written its results.)  Across processes the bounded polls end the wait.
-    static std::mutex mu;
-    static hipEvent_t last[64] = {};
-    std::lock_guard<std::mutex> lock(mu);
-    const int dv2 = c->device & 63;
-    if (!last[dv2] && hipEventCreateWithFlags(&last[dv2], hipEventDisableTiming) != hipSuccess) last[dv2] = nullptr;
-    if (last[dv2]) (void)hipStreamWaitEvent(c->stream, last[dv2], 0);
-    hipLaunchKernelGGL((k_onchip_sweeps<SX, RPW, DBG, PROJ>), dim3(g.G), dim3(ONCHIP_THREADS), g.shmem, c->stream, a);
-    const hipError_t le = hipGetLastError();
-    if (le == hipSuccess && last[dv2]) (void)hipEventRecord(last[dv2], c->stream);
-    return le;
+    return onchip_ordered_launch(c, fn, g.G, g.shmem, a);
 }
 // sweeps [cur .. run_total) in one launch; false: not launched (the caller takes the launch-per-phase schedule)
 bool enqueue_onchip(rri_ctx* c, Cursor cur) {
@@ -1425,6 +1447,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         (void)hipMemsetAsync(c->mkP, 0, (size_t)64 * (k + 1) * 8, c->stream);
     }
     if (!c->mkG || !c->mkP || !c->mkbar) return false;
+    if (!c->Wsafe && hipMalloc((void**)&c->Wsafe, (size_t)k * c->ldw * 8) != hipSuccess) { c->Wsafe = nullptr; return false; }
+    if (!c->Tsafe && hipMalloc((void**)&c->Tsafe, (size_t)k * c->LD * 8) != hipSuccess) { c->Tsafe = nullptr; return false; }
     (void)hipMemsetAsync(c->mkbar, 0, (size_t)(128 + g.G) * sizeof(unsigned), c->stream);
     OnchipArgs a{};
     a.X = c->X; a.ldx = c->ldx; a.n = (int)c->n; a.d = (int)c->d; a.LD = (int)c->LD; a.k = k;
@@ -1454,6 +1478,10 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
             a.dbg = dbg;
         }
     }
+    // what a launch that gives up is rolled back to (0.9 MB at 10000 x 1000, k = 20: two copies of a few microseconds)
+    (void)hipMemcpyAsync(c->Wsafe, c->W, (size_t)k * c->ldw * 8, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(c->Tsafe, c->T, (size_t)k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream);
+    c->onchip_saved_skip = c->skip_row_finish;
     hipError_t e;
     {
         TimedLaunch tl{nullptr, nullptr};
@@ -1475,6 +1503,7 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         return false;
     }
     c->onchip_launches += 1;
+    c->onchip_in_flight = true;
     if (const char* path = getenv("RRI_ONCHIP_LOG")) {      // tests: which configurations took this path (one line per launch)
         if (FILE* f = fopen(path, "a")) {
             fprintf(f, "%lld %lld %d %s %s sweeps %d..%d\n", (long long)c->n, (long long)c->d, k, c->dtype == RRI_F32 ? "f32" : "f64",
@@ -1636,6 +1665,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     if (const char* e = getenv("RRI_FUSE_W")) g_fuse_w = atoi(e) != 0;
     if (const char* e = getenv("RRI_ONCHIP")) g_onchip = atoi(e) != 0;
+    g_onchip_coop = 0;
+    if (const char* e = getenv("RRI_ONCHIP_COOP")) g_onchip_coop = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_IL")) g_wpass_il = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_SP_MERGE")) g_sp_merge = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_UC")) g_wpass_uc = atoi(e) == 4 ? 4 : 8;
@@ -1801,7 +1832,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkbar, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -2152,12 +2183,37 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
 // ---- the hot path ------------------------------------------------------------------------------------
 static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done) {
     HIPCHK(c, hipSetDevice(c->device));
+    c->onchip_in_flight = false;
     enqueue_from(c, from);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(c, RRI_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
     DevState s;
     rri_status r = read_state(c, &s);
     if (r != RRI_OK) return r;
+    if (c->onchip_in_flight && s.halt == HALT_ERR_GRID_SYNC) {
+        // The persistent launch gave up: its workgroups did not all run at the same time within the bound of the polls (a
+        // device shared with another process, CUs masked away).  The reference's sweep cannot fail for scheduling reasons
+        // (nmf.py:415-476), so neither may this one: W and T go back to what they were before the launch, and the same
+        // range of steps runs on the launch-per-phase schedule, which needs no co-residency.  The handle stays there.
+        c->onchip_in_flight = false;
+        c->onchip_fallbacks += 1;
+        c->onchip_off = true;
+        if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: the persistent sweep gave up; sweeps %d.. rerun launch by launch\n", from.sweep);
+        HIPCHK(c, hipMemcpyAsync(c->W, c->Wsafe, (size_t)c->k * c->ldw * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->T, c->Tsafe, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
+        invalidate(c);
+        c->pending_wcheck = false;
+        c->skip_row_finish = c->onchip_saved_skip;
+        r = clear_halt(c);
+        if (r != RRI_OK) return r;
+        enqueue_range(c, from, c->run_total);
+        enqueue_final_check(c, c->run_total);
+        le = hipGetLastError();
+        if (le != hipSuccess) return fail(c, RRI_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+        r = read_state(c, &s);
+        if (r != RRI_OK) return r;
+    }
+    c->onchip_in_flight = false;
     return status_from_halt(c, s, sweeps_done);
 }
 
@@ -3053,6 +3109,12 @@ rri_status rri_onchip_info(rri_ctx* c, int32_t* eligible, int64_t* launches) {
     CHECK_CTX(c);
     if (eligible) *eligible = (c->have_X && c->have_params && onchip_ok(c)) ? 1 : 0;
     if (launches) *launches = c->onchip_launches;
+    return RRI_OK;
+}
+
+rri_status rri_onchip_fallbacks(rri_ctx* c, int64_t* fallbacks) {
+    CHECK_CTX(c);
+    if (fallbacks) *fallbacks = c->onchip_fallbacks;
     return RRI_OK;
 }
 

@@ -577,6 +577,12 @@ class RRIEngine(object):
         self._check(self._lib.rri_onchip_info(self._h, C.byref(el), C.byref(n)))
         return bool(el.value), int(n.value)
 
+    def onchip_fallbacks(self):
+        """how many persistent launches of this handle gave up (workgroups not co-resident) and were rerun launch by launch"""
+        n = C.c_int64(0)
+        self._check(self._lib.rri_onchip_fallbacks(self._h, C.byref(n)))
+        return int(n.value)
+
     def synchronize(self):
         self._check(self._lib.rri_synchronize(self._h))
 

@@ -177,21 +177,114 @@ def test_many_sweeps_in_one_launch_and_a_later_call_continue_the_same_run():
     assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10
 
 
-def test_a_grid_that_cannot_synchronise_returns_an_error_instead_of_hanging(monkeypatch):
-    """the hand-overs poll a bounded number of times; RRI_ONCHIP_SPIN_LIMIT=0 makes the first unsatisfied poll give up:
-    the abort word takes every workgroup to the end of the kernel and the call reports RRI_ERR_HIP"""
+@pytest.mark.parametrize('flags', [{}, dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)], ids=['plain', 'topic-model'])
+def test_a_grid_that_cannot_synchronise_falls_back_to_the_launch_per_phase_schedule(monkeypatch, flags):
+    """the hand-overs poll a bounded number of times; RRI_ONCHIP_SPIN_LIMIT=0 makes the first unsatisfied poll give up, as a
+    grid whose workgroups are not all resident would.  The reference's sweep cannot fail for scheduling reasons
+    (nmf.py:415-476): the call must COMPLETE -- W, T as before the launch, the same steps launch by launch -- with the result
+    of the launch-per-phase schedule, and count the fallback; the handle then stays on that schedule."""
     n, d, k = 3000, 800, 6
     X = planted_X(n, d, k, seed=71, dtype=np.float32)
     W0, T0 = scaled_init(X, k, seed=72)
+    Wb, Tb, _, _ = run(X, W0, T0, 2, False, **flags)
+    Wb5, Tb5, _, _ = run(X, W0, T0, 5, False, **flags)
     monkeypatch.setenv('RRI_ONCHIP_SPIN_LIMIT', '0')
     with onchip(True), engine(n, d, k, dtype=np.float32) as e:
-        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
-        with pytest.raises(RuntimeError, match='synchronise'):
-            e.sweep(2)
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+        assert e.onchip_info()[0] is True
+        e.sweep(2)
+        assert e.onchip_fallbacks() == 1 and e.onchip_info() == (False, 1)
+        Wa, Ta = e.get_W(), e.get_T()
+        # bit for bit what the launch-per-phase schedule gives: the half-run persistent launch left nothing behind
+        assert np.array_equal(Wa, Wb) and np.array_equal(Ta, Tb), (relfro(Wa, Wb), relfro(Ta, Tb))
+        e.sweep(3)                                              # stays on the launch-per-phase schedule: no further attempt
+        assert e.onchip_fallbacks() == 1 and e.onchip_info() == (False, 1)
+        assert np.array_equal(e.get_W(), Wb5) and np.array_equal(e.get_T(), Tb5)
     monkeypatch.delenv('RRI_ONCHIP_SPIN_LIMIT')
-    Wa, Ta, _, _ = run(X, W0, T0, 2, True)                  # the device and the library are fine afterwards
-    Wb, Tb, _, _ = run(X, W0, T0, 2, False)
-    assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10
+    Wc, Tc, _, _ = run(X, W0, T0, 2, True, **flags)           # the device and the library are fine afterwards
+    assert relfro(Wc, Wb) < 1e-10 and relfro(Tc, Tb) < 1e-10
+
+
+def test_a_fallback_when_a_paused_run_resumes_takes_over_at_the_same_half_step(monkeypatch):
+    """a run interrupted by a T-row reset resumes in the W half of that topic (cursor phase 1, the row checks of the resumed
+    step skipped).  When THAT persistent launch gives up, the launch-per-phase schedule must take over at exactly that
+    half step: same events afterwards, same result as a handle that never left the launch-per-phase schedule."""
+    import ctypes as C
+    from rri_nmf_amd import _capi
+    n, d, k = 600, 200, 4
+    X = planted_X(n, d, k, seed=31, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=32)
+    flags = dict(t_row_sum=1.0, reg_t_l1=1e6)               # every T row is driven to zero: a reset event per topic step
+
+    def drive(e, give_up_from_event):
+        done, events = C.c_int32(0), 0
+        st = e._lib.rri_sweep(e._h, 2, C.byref(done))
+        while st == _capi.RRI_PAUSED:
+            e._resolve_event()
+            events += 1
+            if events == give_up_from_event:
+                monkeypatch.setenv('RRI_ONCHIP_SPIN_LIMIT', '0')
+            st = e._lib.rri_resume(e._h, C.byref(done))
+        e._check(st)
+        monkeypatch.delenv('RRI_ONCHIP_SPIN_LIMIT', raising=False)
+        return e.get_W(), e.get_T(), events, list(e.reset_log)
+
+    out = []
+    for on, give_up in ((True, 1), (False, -1)):
+        with onchip(on), engine(n, d, k, dtype=np.float32) as e:
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+            out.append(drive(e, give_up) + (e.onchip_fallbacks(), e.onchip_info()[1]))
+    (Wa, Ta, ea, la, fa, na), (Wb, Tb, eb, lb, fb, nb) = out
+    assert fa == 1 and na == 2 and fb == 0 and nb == 0, (fa, na, fb, nb)      # two persistent launches, the second gave up
+    assert ea == eb >= k and la == lb
+    assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10, (relfro(Wa, Wb), relfro(Ta, Tb))
+
+
+def test_two_handles_of_different_instantiations_on_two_streams_are_ordered():
+    """every persistent launch of a process waits for the one before it on the same device, whatever its template
+    instantiation (round 2 kept the mutex and the event inside the template: an fp32 and a float64 handle, or a plain and a
+    topic-model one, were not ordered and could each hold half of the CUs).  Four handles -- fp32 plain (20 rows per wave),
+    fp32 topic model, float64 plain, fp32 small (8 rows per wave) -- sweep from four threads at once, several calls each;
+    nothing may give up and every result equals the handle's own sequential run."""
+    import threading
+    cases = [((10000, 1000, 20), np.float32, {}), ((6000, 1000, 12), np.float32, TM), ((5000, 1000, 10), np.float64, {}),
+             ((2000, 512, 6), np.float32, {})]
+    data = []
+    for (n, d, k), dt, flags in cases:
+        X = planted_X(n, d, k, seed=n + k, dtype=np.float32)
+        W0, T0 = scaled_init(X, k, seed=91)
+        data.append((X.astype(dt), W0, T0, dt, flags))
+    want = [run(X, W0, T0, 6, True, dtype=dt, **flags)[:2] for X, W0, T0, dt, flags in data]
+    got, errs = [None] * len(data), []
+
+    def work(i):
+        try:
+            X, W0, T0, dt, flags = data[i]
+            n, d = X.shape
+            e = engines[i]
+            for _ in range(3):
+                e.sweep(2)
+            got[i] = (e.get_W(), e.get_T(), e.onchip_info()[1], e.onchip_fallbacks())
+        except Exception as ex:      # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    with onchip(True):
+        engines = []
+        for X, W0, T0, dt, flags in data:
+            e = engine(X.shape[0], X.shape[1], W0.shape[1], dtype=dt)
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+            assert e.onchip_info()[0] is True
+            engines.append(e)
+    try:
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(data))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+    finally:
+        [e.close() for e in engines]
+    assert not errs, errs
+    for i, (Wg, Tg, launches, fallbacks) in enumerate(got):
+        assert launches == 3 and fallbacks == 0, (i, launches, fallbacks)
+        assert np.array_equal(Wg, want[i][0]) and np.array_equal(Tg, want[i][1]), (i, relfro(Wg, want[i][0]))
 
 
 TM = dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)
@@ -228,7 +321,10 @@ def test_topic_model_flags(shape):
     perm = np.random.RandomState(0).permutation(d)
     ctl = orc.nmf(np.ascontiguousarray(X64[:, perm]), k, W_in=W64.copy(), T_in=np.ascontiguousarray(T64[:, perm]), **kw)
     sens = max(relfro(ctl['T'], ref['T'][:, perm]), relfro(ctl['W'], ref['W']))
-    tol = max(2e-9, 50 * sens)
+    # ... but never beyond a FIXED bound: 1e-7 is fifty times what the launch-per-phase schedule holds on the worst of these
+    # shapes, so a regression of two orders of magnitude cannot hide behind a large control
+    tol = min(max(2e-9, 50 * sens), 1e-7)
+    print('topic-model flags %r: control (oracle vs its column permutation) %.2e, bound %.2e' % (shape, sens, tol))
     for Tg, Wg in ((Ta, Wa), (Tb, Wb)):
         assert relfro(Tg, ref['T']) < tol and relfro(Wg, ref['W']) < tol, (relfro(Tg, ref['T']), relfro(Wg, ref['W']), sens)
 
@@ -286,7 +382,9 @@ def test_float64_storage(shape, flags):
     ref = orc.nmf(X, k, W_in=W0.copy(), T_in=T0.copy(), **kw)
     perm = np.random.RandomState(0).permutation(d)
     ctl = orc.nmf(np.ascontiguousarray(X[:, perm]), k, W_in=W0.copy(), T_in=np.ascontiguousarray(T0[:, perm]), **kw)
-    tol = max(2e-9, 50 * max(relfro(ctl['T'], ref['T'][:, perm]), relfro(ctl['W'], ref['W'])))
+    sens = max(relfro(ctl['T'], ref['T'][:, perm]), relfro(ctl['W'], ref['W']))
+    tol = min(max(2e-9, 50 * sens), 1e-7)                    # measured control, capped by a fixed bound
+    print('float64 storage %r %s: control %.2e, bound %.2e' % (shape, 'topic-model' if flags else 'plain', sens, tol))
     assert relfro(Ta, ref['T']) < tol and relfro(Wa, ref['W']) < tol, (relfro(Ta, ref['T']), relfro(Wa, ref['W']), tol)
 
 

@@ -405,13 +405,11 @@ def main():
     mask_packed = weighted and os.environ.get('RRI_MASK_BITS', '1') != '0'
     arrays_per_launch = (((3.0 + 2.0 / 32.0) if mask_packed else 5.0) / 2.0) if weighted else (2.0 if resid_sched else 1.0)
     bytes_per_launch = float(n_local) * d * es * arrays_per_launch
-    sp_merge = os.environ.get('RRI_SP_MERGE', '1') != '0'
-    sp_step_bytes = (2.0 * (2.0 + 2.0 * es)) if sp_merge else (6.0 + 5.0 * es)     # fp32: 20 B (26 B with the dense flavour's schedule)
+    sp_step_bytes = 2.0 * (2.0 + 2.0 * es)     # fp32: 20 B per observed entry and topic step
     if sparse:
         # per topic step and observed entry: ONE read-modify-write pass over each of the two copies of the pattern
         # residual, (uint16 offset + value read, value written) = 2 + 4 + 4 B each at fp32 -> 20 B per step, 10 B per
-        # timed launch (the factor tables, staged in LDS once per workgroup, are not counted).  RRI_SP_MERGE=0: the
-        # schedule shared with the dense flavour, a read pass (6 B) and two read-modify-write passes: 26 B, 13 per pass
+        # timed launch (the factor tables, staged in LDS once per workgroup, are not counted)
         bytes_per_launch = sp_step_bytes / 2.0 * nnz
     # launch-bound sizes whose X fits the chip's registers run whole calls as ONE persistent launch (rri_onchip_kernels.hpp):
     # that launch processes steps * k topic steps, each worth n*d*s algorithmic bytes -- none of which moves through HBM

@@ -51,17 +51,6 @@ struct Cursor {
     int sweep, topic, phase;  // phase 0 = T-row half, 1 = W-column half
 };
 
-// host-side flags that describe the state BETWEEN two sweeps (captured sweeps, below)
-struct SteadyState {
-    bool carry_valid, pending_wcheck, resid_valid, resid_fresh, dt_pending, q_valid, skip_row_finish, xy_valid;
-    int carry_topic, pending_wcheck_topic, xy_run;
-    bool operator==(const SteadyState& o) const {
-        return carry_valid == o.carry_valid && pending_wcheck == o.pending_wcheck && resid_valid == o.resid_valid &&
-               resid_fresh == o.resid_fresh && dt_pending == o.dt_pending && q_valid == o.q_valid &&
-               skip_row_finish == o.skip_row_finish && carry_topic == o.carry_topic &&
-               (!pending_wcheck || pending_wcheck_topic == o.pending_wcheck_topic);
-    }
-};
 struct TimedLaunch {
     hipEvent_t a, b;
 };
@@ -188,8 +177,7 @@ struct rri_ctx {
 
     int npanels = 1, rpb = 1, nrb = 1, nwb = 1, ntb = 1;
     int gpart_n = 1;   // rows of Gpart its last writer left (k_wcol: nwb, k_wcol_resid: nwb256, fused pass: nrb)
-    int ttpart_n = 0;  // partial vectors T T[t]^T in Ttpart (k_tgram: nsplit; k_trow_small for the fused W update: ntb32)
-    int ttpart_topic = -1;   // topic whose k_trow_small left them (the fused W update needs them fresh)
+    int ttpart_n = 0;  // partial vectors T T[t]^T in Ttpart (k_tgram: nsplit)
     int xy_rows = 0;   // blocks per topic in XYpart (stride xy_stride)
     int xy_stride = 1;
     int ntb32 = 1;     // 32-column blocks of k_trow_small
@@ -198,12 +186,6 @@ struct rri_ctx {
     rri_params prm{};
     bool have_params = false, have_X = false, have_W = false, have_T = false, have_M = false;
 
-    // one steady-state sweep captured into a hipGraph (launch-bound sizes): valid while nothing that shapes the
-    // sequence of launches changes (parameters, bound buffers); graph_entry / graph_exit: the host flags it needs
-    // at its start and leaves at its end
-    hipGraphExec_t graph_exec = nullptr;
-    SteadyState graph_entry{}, graph_exit{};
-    long graph_replays = 0;
 
     bool carry_valid = false;
     int carry_topic = -1;
@@ -415,31 +397,22 @@ int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (nee
 int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
 int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted pass with a bit-packed mask: 8 (one mask word per
                          // chunk; +1.3 % at C5 over 4, 16 falls to one wave per SIMD: profiles/r02_weighted_pass_variants.log) or 4
-int g_sp_merge = 1;      // RRI_SP_MERGE=0: pattern-only handles run the dense flavour's schedule (row copy: read pass + write pass)
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_onchip = 1;       // RRI_ONCHIP=0: never the register-resident persistent sweep (rri_onchip_kernels.hpp)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
-int g_graph = 0;         // RRI_GRAPH: 0 never capture sweeps (default: measured, it does not pay here), 1 for
-                        // launch-bound sizes, 2 always
 int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
 int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
                              // interleaved up to 1024 workgroups (+2 % at 20000 x 5000; -1 % at C3, where it stays off)
+int g_pass_rot = 0;      // RRI_PASS_ROT=1..7 (diagnostics): rotate the tiles of k_pass inside every group of 8 workgroups (another XCD per tile)
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
-int g_fuse_w = 0;       // RRI_FUSE_W=1: the W-column update in the epilogue of the pass where a workgroup sees whole rows (two
-                        // launches per topic step instead of three).  Measured at 10000 x 1000, k = 20: 1865 against 1937 sweeps/s --
-                        // the epilogue is as long as the launch it saves (profiles/r02_c2_variants.log).  Off by default.
-
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
 template <typename SX>
 struct LaunchX {
     typedef SX Elem;
     // row-dot slots of the 4 waves, the active W column, (UPD: one or two arrays of rank-one row factors,) the row-sum tiles
-    static size_t pass_shmem(const rri_ctx* c, int upd, bool fw = false) {
-        // fused W-column update: T T[t]^T (k) and its partials (ntb32 k), the Gram partial (k + 2), the row dots (rpb), the
-        // block's rows of W (k rpb)
-        return ((5 + upd + (fw ? 1 : 0)) * (size_t)c->rpb + 4 * 8 * 72 +
-                (fw ? 2 * (size_t)c->k + 2 + (size_t)c->ntb32 * c->k + (size_t)c->k * c->rpb + 256 : 0)) * sizeof(double);
+    static size_t pass_shmem(const rri_ctx* c, int upd) {
+        return ((5 + upd) * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double);
     }
     // the rank-one terms a pass folds into the residual before it takes its products (UPD = 1: a, b; UPD = 2: also a2 and
     // b2 - b2sub)
@@ -453,27 +426,18 @@ struct LaunchX {
         if (g_pass_nt >= 0) return g_pass_nt != 0;
         return (double)c->n * (double)c->LD * (double)c->es > 192.0e6;
     }
-    template <bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS, bool FW = false>
-    static void pass_k(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u, const TgramJob& job,
-                       const FuseW& fw = FuseW{}) {
+    template <bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS>
+    static void pass_k(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u, const TgramJob& job) {
         const int ncols = (int)std::min<i64>(ldp, c->LD);
         typedef typename std::conditional<(UPD > 0), SX, const SX>::type XT;
-        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS, FW>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
-                           pass_shmem(c, UPD, FW), c->stream, (XT*)Xp, ldp, (int)c->n, ncols, trow, wc, c->Ypart,
+        hipLaunchKernelGGL((k_pass<SX, DO_Y, DO_Z, UPD, U, NT, RS>), dim3(c->npanels * c->nrb + job.nblocks), dim3(256),
+                           pass_shmem(c, UPD), c->stream, (XT*)Xp, ldp, (int)c->n, ncols, trow, wc, c->Ypart,
                            c->Zpart, c->LD, c->rpb, c->npanels, u.a, u.b, u.a2, u.b2, u.b2sub, (const DevState*)c->st, job,
                            // interleaved row chunks: the workgroups running at one time walk ONE window of the matrix, as a
                            // linear stream does.  Read-only pass: +2 % up to 1024 workgroups, nothing at C3.  Read-modify-write
                            // (UPD): +4-9 % at C3 (profiles/r02_residual_schedule_geometry.log) -- reads and writes of a window
                            // stay in the DRAM pages that are open
-                           (g_pass_interleave == 1 || (g_pass_interleave < 0 && (c->npanels * c->nrb <= 1024 || UPD > 0))) ? c->nrb : 0, fw);
-    }
-    // the pass of topic t with the W-column update of t and the Gram partials of tn in its epilogue (FuseW)
-    static void pass_fused(rri_ctx* c, int t, int tn, const FuseW& fw) {
-        TimedScope ts(c, 0);
-        const double* trow = c->T + (i64)t * c->LD;
-        const double* wc = c->W + (i64)tn * c->ldw;
-        if (pass_nt(c)) pass_k<true, true, 0, 8, true, true, true>(c, c->X, c->ldx, trow, wc, Upd{}, TgramJob{}, fw);
-        else pass_k<true, true, 0, 8, false, true, true>(c, c->X, c->ldx, trow, wc, Upd{}, TgramJob{}, fw);
+                           ((g_pass_interleave == 1 || (g_pass_interleave < 0 && (c->npanels * c->nrb <= 1024 || UPD > 0))) ? c->nrb : 0) | (g_pass_rot << 27));
     }
     template <bool DO_Y, bool DO_Z, int UPD>
     static void pass_cfg(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u = Upd{},
@@ -555,13 +519,12 @@ struct LaunchX {
     template <bool DO_S, bool UPD2, bool WRITE, int LPS>
     static void sp_blk_k(rri_ctx* c, const rri_ctx::SpCopy& cp, const double* B1, const double* B2, const double* V,
                          const double* A1, const double* A2, double* S1, double* S2, i64 lds) {
-        typedef typename SpTab<SX>::type TF;
-        const size_t sh = 3 * (size_t)cp.bw * sizeof(TF);
+        const size_t sh = sp_lds_bytes<SX>(cp.bw);
         static bool attr_set[64] = {};   // per instantiation and device (the attribute belongs to the device's code object)
         const int dv = c->device & 63;
         if (!attr_set[dv]) {
             (void)hipFuncSetAttribute((const void*)k_sp_blk<SX, DO_S, UPD2, WRITE, LPS>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SP_BLOCK_BYTES);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SP_BLOCK_BYTES + 64);
             attr_set[dv] = true;
         }
         if (cp.nwork < 1) return;
@@ -814,12 +777,11 @@ struct LK {  // float64-only kernels
     static bool small(const rri_ctx* c) {
         return g_trow_small && (double)gpart_rows(c) * (c->k + 2) * c->ntb32 <= 4.0e6;
     }
-    static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final, bool leave_ttp = false) {
+    static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
         hipLaunchKernelGGL(k_trow_small, dim3(c->ntb32), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->Zpart, c->nrb, (const double*)c->Gpart, gpart_rows(c), c->red, c->LD, c->xraw,
                            c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st, c->explicit_resid ? 1 : 0,
-                           c->explicit_resid ? c->told : (double*)nullptr, leave_ttp ? c->Ttpart : (double*)nullptr);
-        if (leave_ttp) { c->ttpart_n = c->ntb32; c->ttpart_topic = t; }
+                           c->explicit_resid ? c->told : (double*)nullptr);
         c->tpart_n = c->ntb32;
         trow_final_if_needed(c, t, sweep, force_final);
     }
@@ -834,7 +796,6 @@ struct LK {  // float64-only kernels
     }
     static void tgram(rri_ctx* c, int t, int finish, int sweep) {
         c->ttpart_n = c->nsplit;
-        c->ttpart_topic = -1;
         hipLaunchKernelGGL(k_tgram, dim3(c->k, c->nsplit), dim3(256), 0, c->stream, (const double*)c->T, c->LD,
                            (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n, finish, sweep,
                            kparams(c), c->st);
@@ -958,20 +919,11 @@ rri_status to_host(rri_ctx* c, const void* dev, i64 ldd, void* host, i64 ld, int
 }
 
 void invalidate(rri_ctx* c) {
-    c->ttpart_topic = -1;
     c->carry_valid = false;
     c->carry_topic = -1;
     c->resid_valid = false;
     c->xy_run = -1;
     c->xy_valid = false;
-}
-
-// the captured sweep bakes in the parameters and every buffer address: whatever changes those drops it
-void drop_graph(rri_ctx* c) {
-    if (c->graph_exec) {
-        (void)hipGraphExecDestroy(c->graph_exec);
-        c->graph_exec = nullptr;
-    }
 }
 
 // ---- the topic-step scheduler ------------------------------------------------------------------
@@ -1010,22 +962,13 @@ void enqueue_prologue(rri_ctx* c, int t, int sweep) {
     c->carry_topic = t;
 }
 
-// Launch-bound sizes where one workgroup of the pass sees whole rows (d <= 1024 fp32 columns): the W-column update
-// and the Gram partials of the next topic run in the epilogue of the pass (FuseW) -- two launches per topic step
-// (k_trow_small, k_pass) instead of three.  Needs the T row final when k_trow_small ends (no projection configured).
-bool fused_w_ok(const rri_ctx* c) {
-    return g_fuse_w && !c->weighted && !c->explicit_resid && !c->comm && c->npanels == 1 && c->k >= 2 && LK::light(c) &&
-           !c->prm.fix_W && !c->prm.fix_T && LK::small(c) && g_pass_unroll == 8 && g_pass_rs && g_side_jobs &&
-           (i64)c->ntb32 * c->k <= 256 * FW_NPRE && (i64)c->k * c->rpb <= 256 * FW_NPRE && c->ntb32 <= 256;   // what the epilogue prefetches
-}
-
 void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     if (!c->carry_valid || c->carry_topic != t) enqueue_prologue(c, t, sweep);
     {
         TimedScope ts(c, 2);
         const int chk = c->pending_wcheck ? 1 : 0;
         if (LK::small(c) && !c->comm) {
-            LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone, fused_w_ok(c) && !standalone);
+            LK::trow_small(c, t, chk, c->pending_wcheck_topic, sweep, standalone);
         } else {
             // the one cross-row reduction of a topic step: [w_t^T X | slices of (w_t^T W, ||w_t||^2, sum W[:,t-1])];
             // row-sharded, the ranks all-reduce it here, on the stream, between the two kernels
@@ -1048,22 +991,6 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
     const int tn = (t + 1) % k;
     // T T[t,:]^T for k_wcol; the T-row checks ride along only when a T half of this topic just ran and left its sums.
     // Where a pass follows, the job joins its grid (no launch of its own); with T fixed there is no pass.
-    if (carry_next && fused_w_ok(c) && c->ttpart_topic == t && !c->skip_row_finish) {
-        // the T half of this topic has just run and left T T[t]^T and the row sums: pass + W-column update + Gram
-        // partials of the next topic as ONE launch
-        const FuseW fw{c->W, c->ldw, k, t, tn, (const double*)c->Ttpart, c->ttpart_n, (const double*)c->tpart, c->tpart_n,
-                       c->Gpart, c->XYpart + (i64)t * c->xy_stride, sweep, kparams(c), c->st};
-        DISPATCH(c, L::pass_fused(c, t, tn, fw));
-        c->gpart_n = c->nrb;
-        LK::note_xy(c, t, c->nrb);
-        c->ttpart_topic = -1;
-        c->carry_valid = true;
-        c->carry_topic = tn;
-        c->pending_wcheck = true;
-        c->pending_wcheck_topic = t;
-        c->resid_valid = false;
-        return;
-    }
     const int finish = (LK::light(c) && !c->prm.fix_T && !c->skip_row_finish) ? 1 : 0;
     c->skip_row_finish = false;
     TgramJob job{};
@@ -1074,7 +1001,6 @@ void enqueue_W_half(rri_ctx* c, int sweep, int t) {
         job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n,
                        c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
         c->ttpart_n = c->nsplit;
-        c->ttpart_topic = -1;
     }
     if (carry_next) {
         DISPATCH(c, (L::template pass<true, true>(c, t, tn, job)));
@@ -1169,7 +1095,6 @@ void enqueue_rW_half(rri_ctx* c, int sweep, int t) {
         job = TgramJob{(const double*)c->T, c->LD, (int)c->d, c->k, t, c->Ttpart, (const double*)c->tpart, c->tpart_n,
                        c->nsplit, finish, sweep, kparams(c), c->st, c->k * c->nsplit};
         c->ttpart_n = c->nsplit;
-        c->ttpart_topic = -1;
     }
     const double* trow = c->T + (i64)t * c->LD;
     DISPATCH(c, {
@@ -1275,7 +1200,7 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     const double* b1 = (c->prm.fix_T || !c->dt_pending) ? c->zeros : c->dtv;
     c->dt_pending = false;
     c->resid_fresh = false;
-    const bool sp_merged = c->sparse && g_sp_merge;
+    const bool sp_merged = c->sparse;
     if (sp_merged) {
         // Pattern-only handles keep two copies of the residual, and each copy serves ONE kind of sum: rows -> row
         // products, columns -> column sums.  So the row copy need not be current between its own passes: the W-column
@@ -1318,14 +1243,13 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     c->carry_topic = tn;
 }
 
-// sweeps [cur .. s_end) of the current call; `sweep_arg_offset` is subtracted from the sweep index the kernels are
-// given (a captured sweep is enqueued as sweep 0: DevState.sweep_base carries the rest)
-void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) {
+// sweeps [cur .. s_end) of the current call
+void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
     const int k = c->k;
     if (c->weighted) {
         for (int s = cur.sweep; s < s_end; ++s) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;
-            const int sa = s - sweep_arg_offset;
+            const int sa = s;
             for (int t = t0; t < k; ++t) {
                 const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
                 // once per sweep (and after resets), unless rri_objective has just rebuilt it from the same W, T
@@ -1339,7 +1263,7 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) 
     if (c->explicit_resid) {
         for (int s = cur.sweep; s < s_end; ++s) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;
-            const int sa = s - sweep_arg_offset;
+            const int sa = s;
             for (int t = t0; t < k; ++t) {
                 const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
                 // rebuilt once per sweep (and after anything changed W or T from outside), unless rri_objective has
@@ -1353,7 +1277,7 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end, int sweep_arg_offset = 0) 
     }
     for (int s = cur.sweep; s < s_end; ++s) {
         const int t0 = (s == cur.sweep) ? cur.topic : 0;
-        const int sa = s - sweep_arg_offset;
+        const int sa = s;
         for (int t = t0; t < k; ++t) {
             const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
             if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, sa, t, c->prm.fix_W != 0);
@@ -1517,7 +1441,6 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     c->carry_valid = false; c->carry_topic = -1;
     c->pending_wcheck = false;
     c->resid_valid = false; c->q_valid = false;
-    c->ttpart_topic = -1;
     c->skip_row_finish = false;
     c->xy_run = whole_last ? k : -1;
     c->xy_rows = g.G;
@@ -1536,25 +1459,6 @@ void enqueue_from(rri_ctx* c, Cursor cur) {
     if (cur.sweep < c->run_total && onchip_ok(c) && enqueue_onchip(c, cur)) return;
     enqueue_range(c, cur, c->run_total);
     enqueue_final_check(c, c->run_total);
-}
-
-// ---- captured sweeps (hipGraph) ------------------------------------------------------------------------------
-// A sweep of a small problem is a few hundred launches of a few microseconds each: launch-bound.  In the steady
-// state (the sweep before left its carry for topic 0, nothing changed from outside) every sweep enqueues the same
-// launches with the same arguments, so ONE sweep is captured into a hipGraph and replayed.  The host-side flags
-// that describe the state between sweeps are compared before a replay and restored after it.
-// Measured on ROCm 7.2 / MI355X (tools/graph_probe.py, profiles/r01_graph_probe.txt): +1 % (10000 x 1000, k = 20) to
-// +7 % (2000 x 500, k = 10) for back-to-back sweeps, -10 % for nmf()'s sweep + objective loop: the gaps between
-// dependent kernels are on the GPU side, the eager launches already run ahead of it.  Off unless RRI_GRAPH is set.
-SteadyState steady_of(const rri_ctx* c) {
-    return SteadyState{c->carry_valid, c->pending_wcheck, c->resid_valid, c->resid_fresh, c->dt_pending, c->q_valid,
-                       c->skip_row_finish, c->xy_valid, c->carry_topic, c->pending_wcheck_topic, c->xy_run};
-}
-void restore_steady(rri_ctx* c, const SteadyState& s) {
-    c->carry_valid = s.carry_valid; c->pending_wcheck = s.pending_wcheck; c->resid_valid = s.resid_valid;
-    c->resid_fresh = s.resid_fresh; c->dt_pending = s.dt_pending; c->q_valid = s.q_valid;
-    c->skip_row_finish = s.skip_row_finish; c->xy_valid = s.xy_valid; c->carry_topic = s.carry_topic;
-    c->pending_wcheck_topic = s.pending_wcheck_topic; c->xy_run = s.xy_run;
 }
 
 rri_status read_state(rri_ctx* c, DevState* out) {
@@ -1606,8 +1510,21 @@ rri_status status_from_halt(rri_ctx* c, const DevState& s, int32_t* sweeps_done)
 }
 
 rri_status clear_halt(rri_ctx* c) {
-    HIPCHK(c, hipMemsetAsync(c->st, 0, 32, c->stream));  // halt, halt_topic, halt_sweep, halt_pos, tmode, proj_iters, sweep_base
+    HIPCHK(c, hipMemsetAsync(c->st, 0, 32, c->stream));  // halt, halt_topic, halt_sweep, halt_pos, tmode, proj_iters
     return RRI_OK;
+}
+
+// The big read-modify-write buffers (the residual R / E).  RRI_MALLOC_CONTIGUOUS=1 (diagnostics, tools/rmw_place.py) asks the
+// runtime for physically contiguous memory (hipExtMallocWithFlags, hipDeviceMallocContiguous).
+int g_malloc_contig = 0;
+hipError_t big_malloc(void** p, size_t bytes) {
+    if (g_malloc_contig) {
+        hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: contiguous allocation of %zu bytes refused (%s); plain hipMalloc\n", bytes, hipGetErrorString(e));
+    }
+    return hipMalloc(p, bytes);
 }
 
 rri_status ready(rri_ctx* c) {
@@ -1652,23 +1569,24 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     // the switches are per process and read again by every rri_create: an unset variable means the default, not "what
     // the last handle was created with"
     g_pass_unroll = 8; g_pass_unroll_upd = 16; g_pass_nt = -1; g_pass_rs = 1; g_obj_direct = 0; g_pass_interleave = -1;
-    g_trow_small = 1; g_graph = 0; g_resid_mfma = 1; g_side_jobs = 1; g_fuse_w = 0; g_onchip = 1; g_wpass_il = -1;
-    g_sp_merge = 1; g_wpass_uc = 8;
+    g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_wpass_il = -1;
+    g_wpass_uc = 8;
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_IL")) g_pass_interleave = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_TROW_SMALL")) g_trow_small = atoi(e) != 0;
-    if (const char* e = getenv("RRI_GRAPH")) g_graph = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
-    if (const char* e = getenv("RRI_FUSE_W")) g_fuse_w = atoi(e) != 0;
     if (const char* e = getenv("RRI_ONCHIP")) g_onchip = atoi(e) != 0;
     g_onchip_coop = 0;
+    g_pass_rot = 0;
+    if (const char* e = getenv("RRI_PASS_ROT")) g_pass_rot = atoi(e) & 7;
+    g_malloc_contig = 0;
+    if (const char* e = getenv("RRI_MALLOC_CONTIGUOUS")) g_malloc_contig = atoi(e) != 0;
     if (const char* e = getenv("RRI_ONCHIP_COOP")) g_onchip_coop = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_IL")) g_wpass_il = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("RRI_SP_MERGE")) g_sp_merge = atoi(e) != 0;
     if (const char* e = getenv("RRI_WPASS_UC")) g_wpass_uc = atoi(e) == 4 ? 4 : 8;
     c->PW = 64 * c->VN * 4;   // columns per workgroup: 4 waves x (64 lanes x 16 B)
     c->LD = round_up(d, c->VN);
@@ -1779,7 +1697,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (weighted) {
         const i64 zn = std::max<i64>(c->LD, n);
         if (!c->sparse) {
-            CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+            CR(big_malloc(&c->E, (size_t)n * c->LD * es_x));
             // k_resid writes the d real columns only; the passes stream all LD: the pad columns must hold zeros
             // (recycled memory there once held NaN patterns, which fmax(numer, 0) turned into zero rows of W)
             if (c->LD != d) CR(hipMemsetAsync(c->E, 0, (size_t)n * c->LD * es_x, c->stream));
@@ -1801,7 +1719,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     }
     if (explicit_resid) {
         const i64 zn = std::max<i64>(c->LD, n);
-        CR(hipMalloc(&c->E, (size_t)n * c->LD * es_x));
+        CR(big_malloc(&c->E, (size_t)n * c->LD * es_x));
         if (c->LD != d) CR(hipMemsetAsync(c->E, 0, (size_t)n * c->LD * es_x, c->stream));   // pad columns stay zero
         CR(hipMalloc((void**)&c->dwv, (size_t)n * f8));
         CR(hipMemsetAsync(c->dwv, 0, (size_t)n * f8, c->stream));
@@ -1825,7 +1743,6 @@ rri_status rri_destroy(rri_ctx* c) {
     if (!c) return RRI_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    drop_graph(c);
     if (c->own_X) (void)hipFree(c->X);
     if (c->own_M) (void)hipFree(c->M);
     void* bufs[] = {c->E, (void*)c->W, (void*)c->T, (void*)c->Wprev, (void*)c->Tprev,                     (void*)c->Ypart, (void*)c->Zpart, (void*)c->xraw, (void*)c->Ttpart, (void*)c->Gpart,
@@ -1849,7 +1766,6 @@ rri_status rri_destroy(rri_ctx* c) {
 // ---- data ------------------------------------------------------------------------------------------
 rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->X && !c->own_X) c->X = nullptr;
@@ -1866,7 +1782,6 @@ rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_d
 
 rri_status rri_upload_mask(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtype) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1920,7 +1835,6 @@ rri_status csr_to_device(rri_ctx* c, const int64_t* indptr, const int32_t* indic
 rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
                             int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     HIPCHK(c, hipSetDevice(c->device));
     CsrDev dv;
@@ -1952,7 +1866,6 @@ rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* in
 rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* data,
                                        int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1980,7 +1893,6 @@ rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const 
 rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int32_t* indices, const void* values,
                                    int64_t nnz, int32_t data_dtype) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (!c->sparse) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=RRI_WEIGHTED_SPARSE");
     if (nnz >= 2147483647LL) return fail(c, RRI_ERR_UNSUPPORTED, "more than 2^31-1 observed entries");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2010,7 +1922,7 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
         else launch_convert<double, double, false>(c, dv.data, nnz, c->sp_x, nnz, 1, nnz);
     }
     // the two blocked copies: counting sort on the host, stable, so offsets ascend inside a segment
-    int target_items = 3 * 256;
+    int target_items = std::max(1, c->n_cu);
     if (const char* e = getenv("RRI_SP_ITEMS")) target_items = std::max(1, atoi(e));
     for (int w = 0; w < 2; ++w) {
         rri_ctx::SpCopy& cp = c->sp[w];
@@ -2039,7 +1951,7 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
         }
         cp.count = run;
         const size_t cntp = (size_t)std::max<i64>(run, 4);
-        std::vector<unsigned short> bidx(cntp, SP_PAD);
+        std::vector<unsigned short> bidx(cntp, (unsigned short)cp.bw);      // pads: the zero slot of the factor tables
         std::vector<int> perm(cntp, -1);
         {
             std::vector<i64> fill((size_t)cp.nblk * nseg);
@@ -2055,17 +1967,37 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
                     perm[(size_t)q] = (int)p;
                 }
         }
-        // work items: runs of segments of one block holding about nnz / target_items entries (at most 8192 segments)
+        // Work items: runs of segments of one block, at most `target_items` in all and of equal entry count -- ONE round of
+        // workgroups (a 1024-thread workgroup with the block's tables per CU).  Round 2 cut "about 3 x 256" items and got
+        // 774-780: three rounds of the 256 CUs and a fourth for the last few, a quarter of every launch with the chip idle
+        // (profiles/r03_sp_blk_probe.log: 138 -> 115 us per pass).  Every (block, segment) belongs to exactly one item --
+        // also the empty ones, whose sums the consumers still read.
         std::vector<SpWork> work;
-        const i64 per_item = std::max<i64>(4096, nnz / target_items);
-        for (int b = 0; b < cp.nblk; ++b) {
-            const i64* row = sp.data() + (size_t)b * stride;
-            i64 s0 = 0;
-            while (s0 < nseg) {
-                i64 s1 = s0 + 1;
-                while (s1 < nseg && s1 - s0 < 8192 && row[s1 + 1] - row[s0] <= per_item) ++s1;
-                work.push_back(SpWork{b, (int)s0, (int)s1, 0});
-                s0 = s1;
+        {
+            std::vector<i64> eb((size_t)cp.nblk);
+            i64 total = 0;
+            for (int b = 0; b < cp.nblk; ++b) {
+                const i64* row = sp.data() + (size_t)b * stride;
+                eb[(size_t)b] = row[nseg] - row[0];
+                total += eb[(size_t)b];
+            }
+            const i64 spare = std::max<i64>(0, (i64)target_items - cp.nblk);      // every block needs one item; the rest by share
+            for (int b = 0; b < cp.nblk; ++b) {
+                const i64* row = sp.data() + (size_t)b * stride;
+                i64 items_b = 1 + (total > 0 ? spare * eb[(size_t)b] / total : 0);
+                items_b = std::max<i64>(1, std::min<i64>(items_b, eb[(size_t)b] / 4096));      // no items of a few entries
+                i64 s0 = 0;
+                for (i64 j = 1; j <= items_b && s0 < nseg; ++j) {
+                    i64 s1 = nseg;
+                    if (j < items_b) {
+                        const i64 want = row[0] + eb[(size_t)b] * j / items_b;     // first segment boundary at or past the j-th share
+                        s1 = std::lower_bound(row + s0 + 1, row + nseg, want) - row;
+                        s1 = std::min<i64>(std::max<i64>(s1, s0 + 1), nseg);
+                    }
+                    work.push_back(SpWork{b, (int)s0, (int)s1, 0});
+                    s0 = s1;
+                }
+                if (s0 < nseg) work.push_back(SpWork{b, (int)s0, (int)nseg, 0});
             }
         }
         cp.nwork = (int)work.size();
@@ -2100,7 +2032,6 @@ rri_status rri_upload_observed_csr(rri_ctx* c, const int64_t* indptr, const int3
 
 rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
         return fail(c, RRI_ERR_INVALID, "device X must be 16-byte aligned with a 16-byte-multiple row stride >= d");
@@ -2120,7 +2051,6 @@ rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
 
 rri_status rri_bind_mask_device(rri_ctx* c, const void* dev, int64_t ld) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a sparse-pattern handle takes its data through rri_upload_observed_csr");
     if (!c->weighted) return fail(c, RRI_ERR_INVALID, "handle was not created with weighted=1");
     if (!dev || ld < c->d || (ld * (i64)c->es) % 16 || ((uintptr_t)dev) % 16)
@@ -2176,7 +2106,6 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
         return fail(c, RRI_ERR_UNSUPPORTED, "the explicit-residual schedule needs k >= 2 and both halves free");
     c->prm = *p;
     c->have_params = true;
-    drop_graph(c);
     return RRI_OK;
 }
 
@@ -2217,61 +2146,6 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
     return status_from_halt(c, s, sweeps_done);
 }
 
-// launch-bound sizes only: where one streaming pass takes well under ~100 us the gaps between launches show
-static bool graph_wanted(const rri_ctx* c) {
-    if (g_graph == 0 || c->timing > 0 || c->explicit_resid || c->comm) return false;
-    if (g_graph == 2) return true;
-    const double bytes = c->sparse ? 16.0 * (double)c->nnz : (double)c->n * (double)c->LD * (double)c->es;
-    return bytes <= 512e6;
-}
-
-static void enqueue_one_sweep(rri_ctx* c, int s) {   // as sweep 0 of DevState.sweep_base, then move that on
-    enqueue_range(c, Cursor{s, 0, 0}, s + 1, s);
-    hipLaunchKernelGGL(k_sweep_tick, dim3(1), dim3(1), 0, c->stream, c->st);
-}
-
-static rri_status sweep_with_graph(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
-    HIPCHK(c, hipSetDevice(c->device));
-    for (int s = 0; s < n_sweeps; ++s) {
-        const SteadyState here = steady_of(c);
-        if (c->graph_exec && here == c->graph_entry) {
-            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-            restore_steady(c, c->graph_exit);
-            c->graph_replays += 1;
-            continue;
-        }
-        if (!c->graph_exec && s > 0) {
-            // capture the sweep that is due now; it is a steady-state sweep when it leaves the flags it found
-            hipGraph_t g = nullptr;
-            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                enqueue_one_sweep(c, s);
-                ok = hipStreamEndCapture(c->stream, &g) == hipSuccess && g != nullptr;
-            }
-            const SteadyState after = steady_of(c);
-            if (ok && after == here && hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                c->graph_entry = here;
-                c->graph_exit = after;
-            } else {
-                c->graph_exec = nullptr;
-                ok = false;
-            }
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            restore_steady(c, here);          // nothing has run yet: the capture only recorded
-            if (ok) { --s; continue; }        // replay it for this sweep
-        }
-        enqueue_one_sweep(c, s);
-    }
-    enqueue_final_check(c, 0);
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return fail(c, RRI_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
-    DevState st;
-    rri_status r = read_state(c, &st);
-    if (r != RRI_OK) return r;
-    return status_from_halt(c, st, sweeps_done);
-}
-
 rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
     CHECK_CTX(c);
     rri_status r = ready(c);
@@ -2281,7 +2155,6 @@ rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
     c->run_total = n_sweeps;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
-    if (n_sweeps > 0 && graph_wanted(c)) return sweep_with_graph(c, n_sweeps, sweeps_done);
     return run_and_collect(c, Cursor{0, 0, 0}, sweeps_done);
 }
 
@@ -2307,7 +2180,6 @@ static void event_resolved(rri_ctx* c) {
     if (c->pending.kind == RRI_EVENT_RESET_T) c->skip_row_finish = true;
     c->pending.kind = RRI_EVENT_NONE;
     if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
-    drop_graph(c);   // the kernels take resets_left by value
     invalidate(c);
 }
 
@@ -2380,7 +2252,6 @@ rri_status rri_skip_reset(rri_ctx* c) {
     if (!c->paused) return fail(c, RRI_ERR_INVALID, "no pending event");
     c->pending.kind = RRI_EVENT_NONE;
     c->prm.resets_left = 0;
-    drop_graph(c);
     rri_status r = clear_halt(c);
     if (r != RRI_OK) return r;
     return RRI_OK;
@@ -2836,7 +2707,6 @@ rri_status rri_reduce_buffer(rri_ctx* c, void** dev_ptr, int64_t* n_elems) {
 
 rri_status rri_bind_reduce_buffer(rri_ctx* c, void* dev_ptr, int64_t n_elems) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (!dev_ptr || n_elems < c->red_elems || ((uintptr_t)dev_ptr) % 16)
         return fail(c, RRI_ERR_INVALID, "reduce buffer needs >= %lld elements, 16-byte aligned", c->red_elems);
     if (c->own_red && c->red) (void)hipFree(c->red);
@@ -3041,7 +2911,6 @@ rri_status rri_comm_destroy(rri_comm* m) {
 
 rri_status rri_attach_comm(rri_ctx* c, rri_comm* comm, int64_t row_offset, int64_t n_global) {
     CHECK_CTX(c);
-    drop_graph(c);
     if (!comm) {              // detach
         c->comm = nullptr;
         c->row_offset = 0;

@@ -42,8 +42,7 @@ struct DevState {
     int halt_pos;
     int tmode;       // qf_min branch of the current T row: 0 c>0, 1 c<=0 bounds, 2 c<=0 one-hot
     int proj_iters;  // Michelot iterations of the last projection (diagnostic)
-    int sweep_base;  // added to the `sweep` argument of every kernel: a captured sweep (hipGraph) is replayed with the
-                     // arguments it was captured with, k_sweep_tick moves this on after each replay
+    int pad0;
     int pad1;
     double nt1;      // 1-norm of the unprojected T-row solution (qf_min's nx, nmf.py:447)
     double nt;       // ||T[t,:]||^2
@@ -114,20 +113,6 @@ struct TgramJob {
     KParams p; DevState* st;
     int nblocks;          // k * nsplit, or 0: no job
 };
-// The W-column update of topic t and the Gram partials of topic tn in the EPILOGUE of the pass (launch-bound sizes
-// with d <= one workgroup's width, so a workgroup sees whole rows: the row dots X t_t of its rows are complete in its
-// own LDS).  Saves the k_wcol launch of every topic step.  T T[t,:]^T arrives as per-column-block partials from
-// k_trow_small (Ttpart, nsplit of them), the sums of the new T row as tpart (the row checks of nmf.py:757-769 that
-// the Gram-row job does otherwise: every workgroup takes the same verdict and leaves W alone on a reset event).
-constexpr int FW_NPRE = 8;     // values per thread the fused epilogue prefetches: nsplit k and k rpb must be <= 256 FW_NPRE
-struct FuseW {
-    double* Wt; i64 ldw; int k, t, tn;
-    const double* Ttpart; int nsplit;
-    const double* tpart; int ntp;
-    double* Gpart; double* xyp;
-    int sweep; KParams p; DevState* st;
-};
-
 __device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ldt, int d, int k, int t, int l, int split,
                                             int ns, double* __restrict__ Ttpart, const double* __restrict__ tpart,
                                             int nblk, int finish, int sweep, const KParams& p, DevState* st,
@@ -147,7 +132,7 @@ __device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ld
             st->nt1 = (mode == 0) ? ps : 1.0;
             st->sumT = ps;
             if (!(ps > 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0) {
-                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
             }
         }
     }
@@ -160,7 +145,7 @@ __device__ __forceinline__ void tgram_block(const double* __restrict__ T, i64 ld
 // UPD = 0: X is read only.  UPD = 1: R <- R - a b^T.  UPD = 2: R <- R - a b^T - a2 (b2 - b2sub)^T, the two pending
 // rank-one terms of one topic step of the explicit-residual schedule (dw_{t-1} t_{t-1}^T and w_t dt_t^T; b2sub = the
 // T row before its update, so dt is formed in registers).  a, a2 come through LDS, b, b2 live in registers.
-template <typename SX, bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS, bool FW = false>
+template <typename SX, bool DO_Y, bool DO_Z, int UPD, int U, bool NT, bool RS>
 __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0), SX, const SX>::type* __restrict__ X,
                                               i64 ldx, int n, int ncols,
                                               const double* __restrict__ trow, const double* __restrict__ wcol,
@@ -168,13 +153,11 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
                                               int rpb, int npg, const double* __restrict__ avec,
                                               const double* __restrict__ bvec, const double* __restrict__ avec2,
                                               const double* __restrict__ bvec2, const double* __restrict__ bsub2,
-                                              const DevState* __restrict__ st, const TgramJob job, int nrb_il,
-                                              const FuseW fw) {
+                                              const DevState* __restrict__ st, const TgramJob job, int nrb_il_rot) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
     constexpr int PW = 64 * VN;          // columns per wave
-    static_assert(!FW || (DO_Y && DO_Z && UPD == 0), "the fused W-column update rides on the plain Y + Z pass");
     if (st->halt) return;
     if ((int)blockIdx.x < job.nblocks) {
         __shared__ double jscratch[40];
@@ -182,7 +165,13 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
                     job.Ttpart, job.tpart, job.ntb, job.finish, job.sweep, job.p, job.st, jscratch);
         return;
     }
-    const int bid = (int)blockIdx.x - job.nblocks;
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.x (which XCD block 0 gets is not fixed).  `rot` (top bits of
+    // the argument; RRI_PASS_ROT, diagnostics) rotates the tile a workgroup takes inside its group of 8: another XCD for
+    // every tile, nothing else changed.
+    const int nrb_il = nrb_il_rot & 0x07ffffff;
+    const int rot = (int)((unsigned)nrb_il_rot >> 27);
+    int bid = (int)blockIdx.x - job.nblocks;
+    if (rot != 0 && (bid | 7) < (int)gridDim.x - job.nblocks) bid = (bid & ~7) | ((bid + rot) & 7);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ysh = reinterpret_cast<double*>(smem);            // [4 waves][rpb]
     double* wsh = ysh + 4 * rpb;                              // [rpb]
@@ -220,23 +209,6 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
         tv[e] = (DO_Y && ok) ? trow[col + e] : 0.0;
         bv[e] = (UPD > 0 && ok) ? bvec[col + e] : 0.0;
         bv2[e] = (UPD > 1 && ok) ? bvec2[col + e] - bsub2[col + e] : 0.0;
-    }
-    // fused W-column update: its operands -- the partials of T T[t]^T and this block's rows of W -- are fetched now and
-    // sit in registers while the rows stream by, so their latency is not on the path of the epilogue
-    double fpre_t[FW ? FW_NPRE : 1], fpre_w[FW ? FW_NPRE : 1], fpre_s = 0.0;
-    if constexpr (FW) {
-        fpre_s = (int)threadIdx.x < fw.ntp ? fw.tpart[threadIdx.x] : 0.0;     // sums of the new T row per column block (ntp <= 256)
-#pragma unroll
-        for (int q = 0; q < FW_NPRE; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            fpre_t[q] = e < fw.nsplit * fw.k ? fw.Ttpart[e] : 0.0;
-            double wv0 = 0.0;
-            if (e < fw.k * rpb) {
-                const int g = grow(e % rpb);
-                if (g < n) wv0 = fw.Wt[(i64)(e / rpb) * fw.ldw + g];
-            }
-            fpre_w[q] = wv0;
-        }
     }
     if (wave_has_cols) {
         for (int l0 = 0; l0 < rpb; l0 += U) {
@@ -297,96 +269,7 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
     } else if (DO_Y) {
         for (int i = lane; i < rpb; i += 64) ysh[wave * rpb + i] = 0.0;
     }
-    if constexpr (FW) {
-        // ---- W-column update of topic t for this block's rows, Gram partials of topic tn (what k_wcol<true, true> does
-        // in a launch of its own; npg == 1: the four wave partials in ysh are the whole row dot).  Everything it needs
-        // from global memory was fetched into registers BEFORE the row loop (fpre_t, fpre_w): here only LDS is read.
-        const int k = fw.k, t = fw.t, tn = fw.tn;
-        double* tts = tile + 4 * (8 * 72) - wave * (8 * 72);    // [k]          behind the row-sum tiles
-        double* gsh = tts + k;                                   // [k + 2]
-        double* ynew = gsh + k + 2;                              // [rpb]        X t_t per row
-        double* tpre = ynew + rpb;                               // [nsplit][k]  partials of T T[t]^T
-        double* wtile = tpre + fw.nsplit * k;                    // [k][rpb]     this block's rows of W, k-major
-#pragma unroll
-        for (int q = 0; q < FW_NPRE; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            if (e < fw.nsplit * k) tpre[e] = fpre_t[q];
-            if (e < k * rpb) wtile[e] = fpre_w[q];
-        }
-        for (int l = threadIdx.x; l < k + 2; l += 256) gsh[l] = 0.0;
-        if ((int)threadIdx.x < fw.ntp) wtile[k * rpb + threadIdx.x] = fpre_s;
-        __syncthreads();                                         // also: ysh is complete
-        for (int l = threadIdx.x; l < k; l += 256) {
-            double a = 0.0;
-            for (int b = 0; b < fw.nsplit; ++b) a += tpre[b * k + l];      // ascending b, as ordered_sum
-            tts[l] = a;
-        }
-        // the row checks of _project_and_check_reset_t (nmf.py:757-769) for the T row this pass multiplied with: every
-        // workgroup takes the same verdict from the same sums; on a reset event nothing of W is touched
-        double ps = 0.0;
-        for (int b = 0; b < fw.ntp; ++b) ps += wtile[k * rpb + b];
-        const bool event = !(ps > 1e-10) && fw.p.reset_method != RESET_NONE && fw.p.resets_left > 0;
-        if (bid == 0 && threadIdx.x == 0) {
-            DevState* sw = fw.st;
-            sw->nt1 = (sw->tmode == 0) ? ps : 1.0;
-            sw->sumT = ps;
-            if (event) { sw->halt = HALT_EVENT_RESET_T; sw->halt_topic = t; sw->halt_sweep = fw.sweep + sw->sweep_base; sw->halt_pos = t; }
-        }
-        if (event) return;
-        __syncthreads();
-        const double cden = tts[t] + fw.p.reg_w_l2;              // denom = nt + reg_w_l2 (nmf.py:465)
-        int mode = 0;
-        if (!(cden > 0.0)) {                                     // optimization.py:60-67
-            if (fw.p.has_wrs && fw.p.w_row_sum != 0.0) mode = 1;
-            else {
-                if (bid == 0 && threadIdx.x == 0) {
-                    DevState* sw = fw.st;
-                    sw->halt = HALT_ERR_UNBOUNDED; sw->halt_topic = t; sw->halt_sweep = fw.sweep + sw->sweep_base; sw->halt_pos = t;
-                }
-                return;
-            }
-        }
-        for (int li = threadIdx.x; li < rpb; li += 256) {
-            const int g = grow(li);
-            double wnew = 0.0, y = 0.0;
-            if (g < n) {
-                y = (ysh[li] + ysh[rpb + li]) + (ysh[2 * rpb + li] + ysh[3 * rpb + li]);
-                // W (T t)_{-t}: four partial sums over the topics l = q (mod 4), as the four waves of k_wcol take them
-                double dq[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int l = 0; l < k; ++l)
-                    if (l != t) dq[l & 3] = fma(wtile[l * rpb + li], tts[l], dq[l & 3]);
-                const double dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
-                const double numer = (y - dot) - fw.p.reg_w_l1;
-                if (mode == 0) wnew = fmax(numer, 0.0) / (cden + fw.p.eps);
-                else wnew = (-numer + cden < 0.0) ? fw.p.w_row_sum : 0.0;
-                fw.Wt[(i64)t * fw.ldw + g] = wnew;
-            }
-            ynew[li] = y;
-            wtile[t * rpb + li] = wnew;                          // column t of the tile: the NEW entries
-        }
-        __syncthreads();
-        // Gram row of the next topic against every column, wave w owns l = w, w + 4, ...
-        double nwp = 0.0, swp = 0.0, xyp = 0.0;
-        for (int c0 = 0; c0 < rpb; c0 += 64) {
-            const int li = c0 + lane;
-            const bool valid = li < rpb && grow(li) < n;
-            const double wn = valid ? wtile[tn * rpb + li] : 0.0;
-            for (int l = wave; l < k; l += 4) {                  // wave-uniform
-                const double gl = wave_sum<double>(valid ? wn * wtile[l * rpb + li] : 0.0);
-                if (lane == 0) gsh[l] += gl;                     // column l belongs to this wave alone
-            }
-            if (wave == 0) {
-                const double wnew = valid ? wtile[t * rpb + li] : 0.0;
-                nwp += wave_sum<double>(wn * wn);
-                swp += wave_sum<double>(wnew);
-                xyp += wave_sum<double>(valid ? wnew * ynew[li] : 0.0);
-            }
-        }
-        if (wave == 0 && lane == 0) { gsh[k] = nwp; gsh[k + 1] = swp; fw.xyp[bid] = xyp; }
-        __syncthreads();
-        double* gp = fw.Gpart + (i64)bid * (k + 2);
-        for (int l = threadIdx.x; l < k + 2; l += 256) gp[l] = gsh[l];
-    } else if (DO_Y) {
+    if (DO_Y) {
         __syncthreads();
         for (int i = threadIdx.x; i < rpb; i += 256) {
             const int g = grow(i);
@@ -574,7 +457,7 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
             if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;
             else {
                 if (blockIdx.x == 0 && tid == 0) {
-                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
                 }
                 return;
             }
@@ -673,7 +556,7 @@ __global__ __launch_bounds__(256) void k_wcol_resid(double* __restrict__ Wt, i64
             if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;     // optimization.py:60-67
             else {
                 if (blockIdx.x == 0 && threadIdx.x == 0) {
-                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                    st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
                 }
                 return;
             }
@@ -784,7 +667,7 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
         if (ev || err) {
             if (blockIdx.x == 0 && tid == 0) {
                 st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-                st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = t;
             }
             return;
         }
@@ -801,7 +684,7 @@ __global__ __launch_bounds__(128) void k_trow_numer(double* __restrict__ T, i64 
         }
         if (mode < 0) {
             if (blockIdx.x == 0 && tid == 0) {
-                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
             }
             return;
         }
@@ -867,18 +750,12 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
                                                      const double* __restrict__ Gpart, int nwb, double* __restrict__ red,
                                                      i64 ldz, double* __restrict__ xraw, double* __restrict__ tpart,
                                                      i64* __restrict__ tpart_idx, int check_prev, int tprev, int sweep,
-                                                     KParams p, DevState* st, int resid_form, double* __restrict__ told,
-                                                     double* __restrict__ ttp) {
-    // ttp != NULL (no projection configured, so the row written here is final): also leaves this block's share of
-    // T T[t,:]^T -- ttp[block][l] = sum over its 32 columns of T[l,j] T[t,j] -- for the W-column update fused into the
-    // next pass (FuseW), which then needs no Gram-row job
+                                                     KParams p, DevState* st, int resid_form, double* __restrict__ told) {
     if (st->halt) return;
     const int tid = threadIdx.x;
     __shared__ double sh[32 * 33];
     __shared__ double gsh[RRI_MAX_K + 2];
     __shared__ double zs[32];
-    __shared__ double xs[32];
-    double xfin = 0.0;
     const int cc = tid & 31, g = tid >> 5;
     const i64 j = (i64)blockIdx.x * 32 + cc;
     // The three sets of operands of this kernel -- Gram partials, column-sum partials, rows of T -- do not depend on
@@ -892,7 +769,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
         const int r = g + 32 * q;
         zpre[q] = (j < ldz && r < nrb) ? Zpart[(i64)r * ldz + j] : 0.0;
     }
-    double tkeep[4];     // T[g + 32 q][j]: the first round of the (w^T W) T sum (all there is when k <= 128); reused for ttp
+    double tkeep[4];     // T[g + 32 q][j]: the first round of the (w^T W) T sum (all there is when k <= 128)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int l = g + 32 * q;
@@ -921,7 +798,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
         if (ev || err) {
             if (blockIdx.x == 0 && tid == 0) {
                 st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-                st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = t;
             }
             return;
         }
@@ -938,7 +815,7 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
         }
         if (mode < 0) {
             if (blockIdx.x == 0 && tid == 0) {
-                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t;
+                st->halt = mode; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
             }
             return;
         }
@@ -994,7 +871,6 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
             else { x = numer; mx = numer; idx = j; }
             xraw[j] = x;
             if (mode == 1 || (mode == 0 && !project)) T[(i64)t * ldt + j] = x;
-            xfin = x;
         }
         if (mode != 2) {
             const double s = wave_sum<double>(x);
@@ -1002,23 +878,6 @@ __global__ __launch_bounds__(1024) void k_trow_small(double* __restrict__ T, i64
         } else {
             wave_argmax(mx, idx);
             if (tid == 0) { tpart[blockIdx.x] = mx; tpart_idx[blockIdx.x] = idx; }
-        }
-    }
-    if (ttp) {   // uniform over the grid
-        if (tid < 32) xs[tid] = xfin;
-        __syncthreads();
-        const double xc = xs[cc];
-        for (int q = 0; q * 32 < k; ++q) {       // group g takes the topics g, g + 32, ...: one load per thread and round
-            const int l = g + 32 * q;
-            double v = 0.0;
-            if (l < k && j < d) v = (l == t) ? xc * xc : (q < 4 ? tkeep[q] : T[(i64)l * ldt + j]) * xc;
-            // sum over the 32 lanes of this half-wave (= the 32 columns of group g): lanes 31 / 63 hold the totals
-            v += dpp<0xB1, 0xf>(v);
-            v += dpp<0x4E, 0xf>(v);
-            v += dpp<0x141, 0xf>(v);
-            v += dpp<0x140, 0xf>(v);
-            v += dpp<0x142, 0xa>(v);
-            if (cc == 31 && l < k) ttp[(i64)blockIdx.x * k + l] = v;
         }
     }
     if (blockIdx.x == 0 && tid == 0) st->tmode = mode;
@@ -1111,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_trow_final(double* __restrict__ T, i64
         st->nt1 = nx;
         st->sumT = sumT;
         st->proj_iters = iters;
-        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t; }
+        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
     }
 }
 
@@ -1125,12 +984,6 @@ __global__ __launch_bounds__(256) void k_tgram(const double* __restrict__ T, i64
     if (st->halt) return;
     __shared__ double scratch[40];
     tgram_block(T, ldt, d, k, t, blockIdx.x, blockIdx.y, gridDim.y, Ttpart, tpart, nblk, finish, sweep, p, st, scratch);
-}
-
-// end of a captured sweep: the next replay reports its events one sweep later
-__global__ void k_sweep_tick(DevState* st) {
-    if (st->halt) return;
-    st->sweep_base += 1;
 }
 
 // W[:,t] *= nt1 (nmf.py:450-452); only observable when fix_W keeps the column.
@@ -1150,7 +1003,7 @@ __global__ __launch_bounds__(64) void k_check_red(const double* __restrict__ red
         const bool err = !ev && !(sw > 0.0);
         if (ev || err) {
             st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-            st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
+            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
         }
     }
 }
@@ -1168,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_check_wcol(const double* __restrict__ G
         const bool err = !ev && !(a > 0.0);
         if (ev || err) {
             st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-            st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
+            st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
         }
     }
 }

@@ -46,15 +46,38 @@ __device__ __forceinline__ double group_sum(double v) {
 //   e' = e - (A1[s] * B1[g] + [UPD2] A2[s] * B2[g])            g = block offset + idx[p]
 //   WRITE: val[p] = e' (rounded to the storage type; the sums then use the stored value, as the dense pass does)
 //   DO_S : S1[blk][s] = sum e' * V[g] ,  S2[blk][s] = sum V[g]^2
-// Every segment is padded to a multiple of 4 entries (pad offset SP_PAD), so a lane moves 4 consecutive entries
-// per load: 8 bytes of offsets + 16 (fp32) / 32 (fp64) bytes of values, 8 such quads in flight per lane -- about
-// 12 KB of reads in flight per wave; with one entry per load the passes ran at a third of the bandwidth, bound by
-// the round trips of too few bytes in flight.  One segment per group of LPS lanes; 1024 threads share the tables.
-constexpr unsigned short SP_PAD = 0xFFFF;
+// Every segment is padded to a multiple of 4 entries, so a lane moves 4 consecutive entries per load: 8 bytes of offsets +
+// 16 (fp32) / 32 (fp64) bytes of values, up to 8 such quads in flight per lane; with one entry per load the passes ran at
+// a third of the bandwidth.  One segment per group of LPS lanes; 1024 threads share the tables.
+//
+// Round 3 (tools/sp_blk_probe.hip: this kernel, round 2's and the candidates that lost, outside the library on BASELINE
+// config 5's pattern; profiles/r03_sp_blk_probe*.log): 141 -> 100 us per pass at 5e7 entries, 0.44 -> 0.63 of 8 TB/s.
+//   * ONE ROUND OF WORKGROUPS.  The work list had ~3 x 256 items "of equal entry count" -- 774 to 780 in fact: three full
+//     rounds of the 256 CUs (one 1024-thread workgroup each, the LDS tables) and a fourth for the last 6 to 12 items, a
+//     quarter of the launch with 250 CUs idle.  The host now cuts at most n_cu items (rri_upload_observed_csr): 138 -> 115 us.
+//   * PLAIN loads and stores instead of non-temporal ones: 115 -> 100 us (both copies; the read-modify-write of a line it
+//     has just loaded is what the L2 is for).
+//   * pads point at a ZERO SLOT of the tables (offset bw, written by the host when it builds the copies) instead of being
+//     branched around: `if (gi == SP_PAD) continue` had become control flow per ENTRY, each entry's gathers issued, waited
+//     for and consumed before the next entry's were issued (the ISA: lgkmcnt 2, 1, 0 per entry).  -8 % at 774 items.
+//   * {b1, b2} of an offset side by side in one table: one 8-byte gather (ds_read_b64, the bank behaviour of a 4-byte one)
+//     instead of two; SQ_LDS_BANK_CONFLICT 11.9e6 -> 8.0e6, SQ_LDS_IDX_ACTIVE 22.1e6 -> 16.8e6 cycles per launch, time
+//     unchanged within the noise -- the LDS was not what the pass waited for.
+// What did NOT help, measured on the same copies: a software pipeline across segments (the next segment's quads requested
+// before this one is worked on, bounds and factors staged in LDS, dump quads for the idle lanes so that no memory
+// instruction sits under divergent control flow: waves parked on s_waitcnt 67 % -> 20 %, but stalled at ISSUE 66 %, 150-175
+// us); fp32 fused multiply-adds for the two corrections (-25 % vector-ALU instructions, 129.7 against 130.8 us, and a
+// quarter of the stored values an ulp away); requesting the next segment's bounds ahead; starting half of the waves late.
+template <typename SX> struct SpPair;
+template <> struct SpPair<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct SpPair<double> { typedef double type __attribute__((ext_vector_type(2))); };
 template <typename SX> struct SpQuad;
 template <> struct SpQuad<float> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct SpQuad<double> { typedef double type __attribute__((ext_vector_type(4))); };
 typedef unsigned short sp_us4 __attribute__((ext_vector_type(4)));
+// dynamic LDS of k_sp_blk: {b1, b2} pairs and v for bw + 1 offsets (the last one: the zero slot of the pads)
+template <typename SX>
+__host__ __device__ constexpr size_t sp_lds_bytes(int bw) { return (size_t)3 * (bw + 1) * sizeof(typename SpTab<SX>::type); }
 
 template <typename SX, bool DO_S, bool UPD2, bool WRITE, int LPS>
 __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work, const i64* __restrict__ segptr,
@@ -65,18 +88,21 @@ __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work
                                                  const double* __restrict__ A2, double* __restrict__ S1,
                                                  double* __restrict__ S2, i64 lds, const DevState* __restrict__ st) {
     typedef typename SpTab<SX>::type TF;
+    typedef typename SpPair<TF>::type TF2;
     typedef typename SpQuad<SX>::type V4;
     if (st->halt) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    TF* tb1 = reinterpret_cast<TF*>(smem);   // [bw]
-    TF* tb2 = tb1 + bw;                      // [bw]
-    TF* tv = tb2 + bw;                       // [bw]
+    const int bw1 = bw + 1;                        // slot bw: the zero entry the pads point at
+    TF2* tb12 = reinterpret_cast<TF2*>(smem);      // [bw1] {b1, b2}
+    TF* tv = reinterpret_cast<TF*>(tb12 + bw1);    // [bw1]
     const SpWork w = work[blockIdx.x];
     const i64 g0 = (i64)w.blk * bw;
-    for (int g = threadIdx.x; g < bw; g += 1024) {
-        const bool in = g0 + g < gdim;
-        tb1[g] = in ? (TF)B1[g0 + g] : TF(0);
-        if (UPD2) tb2[g] = in ? (TF)B2[g0 + g] : TF(0);
+    for (int g = threadIdx.x; g < bw1; g += 1024) {
+        const bool in = g < bw && g0 + g < gdim;
+        TF2 p;
+        p[0] = in ? (TF)B1[g0 + g] : TF(0);
+        p[1] = (UPD2 && in) ? (TF)B2[g0 + g] : TF(0);
+        tb12[g] = p;
         if (DO_S) tv[g] = in ? (TF)V[g0 + g] : TF(0);
     }
     __syncthreads();
@@ -98,22 +124,31 @@ __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work
             for (int u = 0; u < UNR; ++u) {
                 const i64 qq = q + (i64)u * LPS;
                 if (qq < q1) {
-                    g[u] = __builtin_nontemporal_load(idx4 + qq);
-                    e[u] = __builtin_nontemporal_load(val4 + qq);
+                    g[u] = idx4[qq];
+                    e[u] = val4[qq];
                 } else {
-                    g[u] = sp_us4{SP_PAD, SP_PAD, SP_PAD, SP_PAD};
+                    const unsigned short z = (unsigned short)bw;
+                    g[u] = sp_us4{z, z, z, z};
                     e[u] = V4{SX(0), SX(0), SX(0), SX(0)};
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
+                const i64 qq = q + (i64)u * LPS;
+                if (qq >= q1) break;
                 V4 out = e[u];
+                TF2 f12[4];
+                TF fv[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {                // the gathers of a quad first, then its arithmetic
+                    const int gi = g[u][m];
+                    f12[m] = tb12[gi];
+                    fv[m] = DO_S ? tv[gi] : TF(0);
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const int gi = g[u][m];
-                    if (gi == SP_PAD) continue;
-                    double corr = c1 * (double)tb1[gi];
-                    if (UPD2) corr = fma(c2, (double)tb2[gi], corr);
+                    double corr = c1 * (double)f12[m][0];
+                    if (UPD2) corr = fma(c2, (double)f12[m][1], corr);
                     double x = (double)e[u][m] - corr;
                     if (WRITE) {
                         const SX r = (SX)x;
@@ -121,15 +156,12 @@ __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work
                         x = (double)r;
                     }
                     if (DO_S) {
-                        const double v = (double)tv[gi];
+                        const double v = (double)fv[m];
                         s1 = fma(x, v, s1);
                         s2 = fma(v, v, s2);
                     }
                 }
-                if (WRITE) {
-                    const i64 qq = q + (i64)u * LPS;
-                    if (qq < q1) __builtin_nontemporal_store(out, val4 + qq);
-                }
+                if (WRITE) val4[qq] = out;
             }
         }
         if (DO_S) {

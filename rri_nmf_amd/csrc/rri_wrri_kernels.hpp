@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_wtrow_final(double* __restrict__ T, i6
     const double anyneg = block_sum(pf, scratch);
     const bool project = p.project_T && p.has_trs;
     if (anyneg > 0.0 && !project && !p.has_trs) {     // any(c<0) and s is None and ub is None
-        if (tid == 0) { st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t; }
+        if (tid == 0) { st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
         return;
     }
     double sumT = nx;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void k_wtrow_final(double* __restrict__ T, i6
     if (tid == 0) {
         st->nt1 = nx;
         st->sumT = sumT;
-        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = t; }
+        if (event) { st->halt = HALT_EVENT_RESET_T; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t; }
     }
 }
 
@@ -381,14 +381,14 @@ __global__ __launch_bounds__(256) void k_wwcol(double* __restrict__ Wt, i64 ldw,
 __device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int sweep, int pos, const KParams& p,
                                              DevState* st) {
     if (f > 0.0 && !p.has_wrs) {
-        st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
+        st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
         return;
     }
     const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
     const bool err = !ev && !(a > 0.0);
     if (ev || err) {
         st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
-        st->halt_topic = tprev; st->halt_sweep = sweep + st->sweep_base; st->halt_pos = pos;
+        st->halt_topic = tprev; st->halt_sweep = sweep; st->halt_pos = pos;
     }
 }
 

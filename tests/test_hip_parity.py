@@ -401,41 +401,6 @@ def test_objective_without_a_pass_over_X(store, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('weighted', [False, True])
-def test_captured_sweeps_equal_eager_sweeps(weighted, monkeypatch):
-    """RRI_GRAPH=2: steady-state sweeps are captured into a hipGraph and replayed (off by default: it does not pay on
-    this stack, csrc/rri_hip.hip); same launches, so the same bits -- including a reset event inside a replay"""
-    from rri_nmf_amd.engine import RRIEngine
-    n, d, k = 1500, 420, 6
-    X = planted_X(n, d, k, seed=0, dtype=np.float64)
-    W0, T0 = scaled_init(X, k, seed=1)
-    M = (np.random.RandomState(3).rand(n, d) < 0.3).astype(np.float64)
-    out = {}
-    monkeypatch.setenv('RRI_ONCHIP', '0')               # captured sweeps are the launch-per-phase schedule's
-    for mode in ('0', '2'):
-        monkeypatch.setenv('RRI_GRAPH', mode)
-        for flags in (dict(), dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0), dict(t_row_sum=1.0, reg_w_l1=1e6, n_resets=1000)):
-            if weighted:
-                flags = dict(flags, t_row_sum=1.0)
-                flags.pop('project_T_each_iter', None)
-            with RRIEngine(n, d, k, dtype=np.float64, weighted=weighted) as e:
-                e.upload_X(X * M if weighted else X)
-                if weighted:
-                    e.upload_mask(M)
-                e.set_W(W0), e.set_T(T0)
-                e.set_params(**flags)
-                e.sweep(4)
-                e.sweep(1)
-                o = e.objective()
-                e.sweep(3)
-                out[mode, tuple(sorted(flags))] = (e.get_W(), e.get_T(), o, e.n_resets_used)
-    for (mode, key), v in out.items():
-        if mode == '2':
-            ref = out['0', key]
-            assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]) and v[2] == ref[2] and v[3] == ref[3], key
-
-
-@pytest.mark.gpu
 def test_the_abi_from_plain_c(tmp_path):
     """tests/c/abi_smoke.c: the boundary used by a C program with no Python or torch in the process (gcc, -lrri_hip)"""
     import os
@@ -498,43 +463,3 @@ def test_bench_line_keeps_its_contract():
     sc = j['rank1_update']['schedule']
     assert sc['sweeps_per_s'] > 0 and max(sc['vs_default_schedule_after_4_sweeps'].values()) < 1e-4, sc
     assert j['rank1_update']['achieved'] > 0
-
-
-@pytest.mark.parametrize('dtype', [np.float64, np.float32])
-def test_fused_w_column_update_equals_the_separate_launch(dtype, monkeypatch):
-    """launch-bound sizes with d <= 1024: the W-column update and the next topic's Gram partials run in the epilogue
-    of the pass (two launches per topic step, FuseW); RRI_FUSE_W=0 keeps k_wcol as a launch of its own.  Same
-    arithmetic per row, other partition of the Gram partial sums: equal to rounding, same reset events, same objective"""
-    from rri_nmf_amd.engine import RRIEngine
-    g = load_golden('g6_rare_branches')
-    n, d, k = [int(v) for v in g['shape']]
-    Xr = planted_X(n, d, k, seed=3, dtype=np.float64)
-    W0r, T0r = scaled_init(Xr, k, seed=4)
-    X = planted_X(3001, 1000, 7, seed=0, dtype=np.float64)
-    W0, T0 = scaled_init(X, 7, seed=1)
-    cases = [(X, W0, T0, dict(), 4), (X, W0, T0, dict(reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03), 3),
-             (X, W0, T0, dict(t_row_sum=1.0, w_row_sum=0.7, reg_w_l2=-5.0), 2),          # c <= 0 on the W side: entries at ub
-             (Xr, W0r, T0r, dict(t_row_sum=1.0, reg_t_l1=1e6), 2), (Xr, W0r, T0r, dict(t_row_sum=1.0, reg_w_l1=1e6), 2),
-             (Xr, g['dead_W0'], T0r, dict(t_row_sum=1.0), 2)]
-    out = {}
-    monkeypatch.setenv('RRI_ONCHIP', '0')               # the launch-per-phase schedule is what this option belongs to
-    for mode in ('1', '0'):
-        monkeypatch.setenv('RRI_FUSE_W', mode)          # read when a handle is created
-        for ci, (Xc, Wc, Tc, flags, sweeps) in enumerate(cases):
-            with RRIEngine(Xc.shape[0], Xc.shape[1], Wc.shape[1], dtype=dtype) as e:
-                e.upload_X(Xc), e.set_W(np.maximum(Wc, 0)), e.set_T(Tc), e.set_params(**flags)
-                e.timing_enable(True)
-                e.sweep(sweeps)
-                launches = (e.timing_read(0)[0], e.timing_read(1)[0])
-                o = e.objective()                       # assembled from the cross terms the W halves left
-                e.sweep(1)
-                out[mode, ci] = (e.get_W(), e.get_T(), o, e.n_resets_used, launches)
-    for ci, (Xc, Wc, Tc, flags, sweeps) in enumerate(cases):
-        a, b = out['1', ci], out['0', ci]
-        assert relfro(a[0], b[0]) < 1e-11 and relfro(a[1], b[1]) < 1e-11, (ci, relfro(a[0], b[0]), relfro(a[1], b[1]))
-        assert abs(a[2] - b[2]) <= 1e-10 * abs(b[2]) and a[3] == b[3]
-        if dtype == np.float32 and a[3] == 0:       # fp32 storage: 1024 columns per workgroup, so d = 1000 / 150 qualify
-            kk = Wc.shape[1]
-            assert a[4][1] <= 1 and b[4][1] >= sweeps * kk          # k_wcol only in the prologue of the call
-    ref = oracle().nmf(stored(X, dtype), 7, W_in=W0.copy(), T_in=T0.copy(), max_iter=5, eps_stop=-1)
-    assert relfro(out['1', 0][0], ref['W']) < TOL[dtype] and relfro(out['1', 0][1], ref['T']) < TOL[dtype]

@@ -52,7 +52,7 @@ CONFIGS = {
                      'figure than the dense c5 (SURVEY 8d)'),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
 
 
 def parse():
@@ -465,6 +465,30 @@ def main():
                                           'trow_chain_segment': trow_ms / max(n2, 1)}},
     }
 
+    if sharded:
+        # What the communicator itself saw, per rank, gathered to rank 0: the record that the run really had `world` ranks
+        # connected and how many all-reduces each of them enqueued (timed region + warm-up + the checked one before it).
+        # transport: 'rccl' = ncclAllReduce inside librri_hip.so; 'torch' = the caller-owned protocol over torch.distributed.
+        if group is not None:
+            crank, cworld, ccalls = eng.comm_stats()
+            mine = [float(crank), float(cworld), float(ccalls)]
+            transport = 'rccl' if 'RCCL inside' in collective else 'host-callback (rehearsal)'
+        else:
+            mine = [float(rank), float(dist.get_world_size()), float(drv.allreduce_calls)]
+            transport = 'torch.distributed'
+        if world > 1:
+            tt = torch.tensor(mine, dtype=torch.float64, device=device)
+            allr = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allr, tt)
+            rows = [[float(v) for v in t.cpu()] for t in allr]
+        else:
+            rows = [mine]
+        out['rccl'] = {'transport': transport, 'world': int(rows[0][1]), 'worlds_seen_by_rank': [int(r[1]) for r in rows],
+                       'ranks': [int(r[0]) for r in rows], 'allreduce_calls': int(rows[0][2]),
+                       'allreduce_calls_by_rank': [int(r[2]) for r in rows],
+                       'expected_allreduce_calls_timed_region': int(args.steps * k),
+                       'doubles_per_allreduce': int((2 * d + 2) if weighted else (d + 8 * (k + 2)))}
+
     # HBM bytes of the dominant kernel(s): PMC counters collected by this command under rocprofv3 --pmc (separate
     # FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py) -- a STATIC profile of the build whose source stamp it
     # carries; a stamp that differs from the sources of this run is flagged.  gfx950: FETCH_SIZE counts half the bytes
@@ -474,21 +498,20 @@ def main():
     if os.path.exists(pmc_file):
         try:
             pm = json.load(open(pmc_file))
-            if sparse:      # one timed pass = pass B, or pass C on both copies
-                keys = [kk for kk in pm if 'k_sp_blk<float' in kk]
-                per_launch = 0.5
+            if sparse:      # the timed launches: k_sp_blk on the row copy and on the column copy, alternating
+                keys = [kk for kk in pm if 'k_sp_blk<float' in kk and pm[kk]['launches'] > 10]
             elif weighted:  # passes B and C (the prologue variant runs 3 times per call: left out)
                 keys = [kk for kk in pm if 'k_wpass<float' in kk and pm[kk]['launches'] > 10]
-                per_launch = 0.5
             elif resid_sched:
                 keys = [kk for kk in pm if 'k_pass<float, true, true, 2' in kk]
-                per_launch = 1.0
             elif onchip:    # one launch per call, of whatever --steps was: a per-launch counter of another command says nothing here
                 keys = []
             else:
                 keys = [kk for kk in pm if 'k_pass<float, true, true, 0' in kk]
-                per_launch = 1.0
-            tot = sum(2.0 * pm[kk]['FETCH_SIZE_KB_avg'] + pm[kk]['WRITE_SIZE_KB_avg'] for kk in keys) * 1024.0
+            # average over the timed launches: every instantiation weighs with the launches it had
+            nl = sum(pm[kk]['launches'] for kk in keys)
+            tot = sum((2.0 * pm[kk]['FETCH_SIZE_KB_avg'] + pm[kk]['WRITE_SIZE_KB_avg']) * pm[kk]['launches'] for kk in keys) * 1024.0 / max(nl, 1)
+            per_launch = 1.0
             if keys:
                 out['roofline']['traffic'] = tot * per_launch
                 stamp = pm.get('_source_stamp')

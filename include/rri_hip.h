@@ -176,7 +176,10 @@ rri_status rri_objective(rri_ctx* ctx, double* out);
 /* argmax over topics of every row of W (harden_distributions, matrixops.py:203-209). */
 rri_status rri_argmax_rows(rri_ctx* ctx, int32_t* out_host);
 /* X*T^T clipped reconstruction error on listed entries: RMSE of NMF_RS_Estimator.score /
- * RMSE_val (sklearn_interface.py:85-91,172-182).  idx = (i,j) pairs, vals = ratings. */
+ * RMSE_val (sklearn_interface.py:85-91,172-182).  idx = (i,j) pairs, vals = ratings.
+ * On a handle with a communicator attached the call is collective: (i, j) are this rank's LOCAL rows (count may be 0),
+ * the result is sqrt(sum of squared errors over all ranks / number of entries over all ranks), equal on every rank -- the
+ * early-stop decision of nmf.py:381-407 is then the same everywhere. */
 rri_status rri_masked_rmse(rri_ctx* ctx, const int64_t* ij, const double* vals, int64_t count,
                            double clip_lo, double clip_hi, double* out);
 /* device-side copy of (W,T) for the early-stop rollback of nmf.py:360-363,393-407 */

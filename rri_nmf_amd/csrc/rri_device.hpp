@@ -68,6 +68,18 @@ __device__ __forceinline__ double ordered_sum_acc(double a0, const double* __res
     return a;
 }
 
+// the same sum left in lane 63 only (no readlane: nothing goes through scalar registers -- k_pass keeps 16 row dots per chunk,
+// which as wave-uniform values cost 32 SGPRs and spilled 102 of them in the read-modify-write instantiations)
+template <typename S>
+__device__ __forceinline__ S wave_sum_lane63(S v) {
+    v += dpp<0xB1, 0xf>(v);
+    v += dpp<0x4E, 0xf>(v);
+    v += dpp<0x141, 0xf>(v);
+    v += dpp<0x140, 0xf>(v);
+    v += dpp<0x142, 0xa>(v);
+    v += dpp<0x143, 0xc>(v);
+    return v;
+}
 template <typename S>
 __device__ __forceinline__ S wave_sum(S v) {
     v += dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]

@@ -70,6 +70,7 @@ struct RcclApi {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;     // optional: what a rank that fails between two matched collectives calls
     bool ok = false;
     std::string err;
 };
@@ -84,6 +85,7 @@ RcclApi load_rccl() {
         a.AllGather = (decltype(a.AllGather))dlsym(from, "ncclAllGather");
         a.Broadcast = (decltype(a.Broadcast))dlsym(from, "ncclBroadcast");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(from, "ncclGetErrorString");
+        a.CommAbort = (decltype(a.CommAbort))dlsym(from, "ncclCommAbort");
         return a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.AllGather && a.Broadcast &&
                a.GetErrorString;
     };
@@ -116,6 +118,7 @@ struct rri_comm {
     void* user = nullptr;
     std::vector<double> hbuf, hbuf2;           // host staging of the callback transport
     long n_allreduce = 0;
+    bool aborted = false;                      // a rank left a collective sequence half way: the communicator is unusable
 };
 
 struct rri_ctx {
@@ -275,8 +278,23 @@ void comm_fail(rri_ctx* c, rri_status code, const char* what, const char* detail
         c->err = std::string("collective failed: ") + what + ": " + (detail ? detail : "?");
     }
 }
+// A rank that cannot go on BETWEEN two collectives its peers will still enter (a device error after the all-gather of a
+// reset and before its broadcast) must not simply return: the peers would block inside RCCL with nothing to interrupt them.
+// It aborts the communicator (ncclCommAbort: pending and later collectives of every rank end with an error) and reports.
+// The host-callback transport has no such call; its collectives are host functions of the caller, who owns their time-outs.
+rri_status comm_abort(rri_ctx* c, const char* what, hipError_t e) {
+    rri_comm* m = c->comm;
+    if (m && m->nccl && !m->aborted && rccl_api().CommAbort) {
+        (void)rccl_api().CommAbort(m->nccl);
+        m->nccl = nullptr;
+    }
+    if (m) m->aborted = true;
+    c->comm_status = RRI_OK;
+    return fail(c, RRI_ERR_COMM, "%s failed between two collectives (%s): the communicator was aborted so that the other ranks do not wait", what, hipGetErrorString(e));
+}
 void comm_allreduce(rri_ctx* c, double* dev, i64 count) {
     rri_comm* m = c->comm;
+    if (m && m->aborted) { comm_fail(c, RRI_ERR_COMM, "all-reduce", "the communicator was aborted"); return; }
     if (!m || c->comm_status != RRI_OK) return;
     m->n_allreduce += 1;
     if (m->nccl) {
@@ -295,6 +313,7 @@ void comm_allreduce(rri_ctx* c, double* dev, i64 count) {
 }
 void comm_allgather(rri_ctx* c, const double* dev_send, i64 count, double* dev_recv) {
     rri_comm* m = c->comm;
+    if (m && m->aborted) { comm_fail(c, RRI_ERR_COMM, "all-gather", "the communicator was aborted"); return; }
     if (!m || c->comm_status != RRI_OK) return;
     if (m->nccl) {
         ncclResult_t r = rccl_api().AllGather(dev_send, dev_recv, (size_t)count, ncclDouble, m->nccl, c->stream);
@@ -313,6 +332,7 @@ void comm_allgather(rri_ctx* c, const double* dev_send, i64 count, double* dev_r
 }
 void comm_broadcast(rri_ctx* c, double* dev, i64 count, int root) {
     rri_comm* m = c->comm;
+    if (m && m->aborted) { comm_fail(c, RRI_ERR_COMM, "broadcast", "the communicator was aborted"); return; }
     if (!m || c->comm_status != RRI_OK) return;
     if (m->nccl) {
         ncclResult_t r = rccl_api().Broadcast(dev, dev, (size_t)count, ncclDouble, root, m->nccl, c->stream);
@@ -351,6 +371,13 @@ KParams kparams(const rri_ctx* c) {
     p.eps = q.eps_div;
     return p;
 }
+
+// Does this handle step through its explicit residual?  Only with both halves free: with T (or W) fixed one half of every
+// step is missing, and the Gram form is then the cheaper schedule by far (T fixed: X T^T once, no pass over the matrix per
+// topic at all; W fixed: one read pass per topic instead of a read-modify-write), so a handle of the explicit-residual
+// schedule takes it for such calls -- fold-in (sklearn_interface.py:327-333, nmf.py:417,460) works on either kind of handle.
+// The stored residual is stale afterwards and rebuilt when next needed.
+bool resid_sched(const rri_ctx* c) { return c->explicit_resid && !c->prm.fix_T && !c->prm.fix_W && c->k >= 2; }
 
 bool no_regs(const rri_ctx* c) {
     const rri_params& q = c->prm;
@@ -769,7 +796,7 @@ struct LK {  // float64-only kernels
     static void trow(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
         hipLaunchKernelGGL(k_trow_numer, dim3(c->ntb), dim3(128), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, check_prev, tprev, sweep,
-                           kparams(c), c->st, c->explicit_resid ? 1 : 0, c->explicit_resid ? c->told : (double*)nullptr);
+                           kparams(c), c->st, resid_sched(c) ? 1 : 0, resid_sched(c) ? c->told : (double*)nullptr);
         c->tpart_n = c->ntb;
         trow_final_if_needed(c, t, sweep, force_final);
     }
@@ -780,8 +807,8 @@ struct LK {  // float64-only kernels
     static void trow_small(rri_ctx* c, int t, int check_prev, int tprev, int sweep, bool force_final) {
         hipLaunchKernelGGL(k_trow_small, dim3(c->ntb32), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, c->k, t,
                            (const double*)c->Zpart, c->nrb, (const double*)c->Gpart, gpart_rows(c), c->red, c->LD, c->xraw,
-                           c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st, c->explicit_resid ? 1 : 0,
-                           c->explicit_resid ? c->told : (double*)nullptr);
+                           c->tpart, c->tpart_idx, check_prev, tprev, sweep, kparams(c), c->st, resid_sched(c) ? 1 : 0,
+                           resid_sched(c) ? c->told : (double*)nullptr);
         c->tpart_n = c->ntb32;
         trow_final_if_needed(c, t, sweep, force_final);
     }
@@ -1260,7 +1287,7 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
         }
         return;
     }
-    if (c->explicit_resid) {
+    if (resid_sched(c)) {
         for (int s = cur.sweep; s < s_end; ++s) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;
             const int sa = s;
@@ -1391,10 +1418,11 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         if (dbg) {
             long long h[32];
             if (c->onchip_launches > 0 && hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char* names[8] = {"A loads", "A rest+signal", "wait workers", "B loads", "row dots", "W update", "carry", "hand-over"};
+                static const char* names[14] = {"A loads", "A rest+signal", "wait workers", "B loads", "row dots", "W update", "carry", "hand-over",
+                                                "closed form", "publish slice", "wait slices", "load row", "project", "-"};
                 for (int w = 0; w < 2; ++w) {
                     fprintf(stderr, "rri on-chip sections, workgroup %s (us total):", w == 0 ? "0 (worker)" : "G-1");
-                    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f;", names[i], h[16 * w + i] * 0.01);
+                    for (int i = 0; i < 13; ++i) fprintf(stderr, " %s %.1f;", names[i], h[16 * w + i] * 0.01);
                     fprintf(stderr, "\n");
                 }
             }
@@ -1415,7 +1443,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         if (c->dtype == RRI_F64) {                // 8 registers per row and lane: half the rows of the fp32 instantiations
             if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, true>(c, g, a);
             else e = g.rpw <= 4 ? onchip_launch<double, 4>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2>(c, g, a);
-        } else if (proj) e = g.rpw <= 8 ? onchip_launch<float, 8, false, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, true>(c, g, a);
+        } else if (proj && a.dbg) e = g.rpw <= 8 ? onchip_launch<float, 8, true, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, true, true>(c, g, a);
+        else if (proj) e = g.rpw <= 8 ? onchip_launch<float, 8, false, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, true>(c, g, a);
         else if (a.dbg) e = g.rpw <= 8 ? onchip_launch<float, 8, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, true>(c, g, a);
         else if (g.rpw <= 8) e = onchip_launch<float, 8>(c, g, a);
         else e = onchip_launch<float, ONCHIP_MAX_RPW>(c, g, a);
@@ -2102,10 +2131,16 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
     if (p->has_w_row_sum && !(p->w_row_sum > 0)) return fail(c, RRI_ERR_INVALID, "w_row_sum must be > 0");
     if (p->reset_method < 0 || p->reset_method > 2) return fail(c, RRI_ERR_INVALID, "bad reset_method");
     if (p->fix_W && p->fix_T) return fail(c, RRI_ERR_INVALID, "fix_W and fix_T together leave nothing to update");
-    if (c->explicit_resid && (p->fix_W || p->fix_T || c->k < 2))
-        return fail(c, RRI_ERR_UNSUPPORTED, "the explicit-residual schedule needs k >= 2 and both halves free");
+    const bool form_before = c->have_params && resid_sched(c);
     c->prm = *p;
     c->have_params = true;
+    if (c->explicit_resid && form_before != resid_sched(c)) {
+        // the call that follows steps in the other form: the sums carried between calls belong to the form that left them,
+        // and a residual the Gram form does not maintain is stale
+        invalidate(c);
+        c->dw_pending = false;
+        c->dt_pending = false;
+    }
     return RRI_OK;
 }
 
@@ -2201,8 +2236,10 @@ rri_status rri_apply_reset_max_resid(rri_ctx* c, int32_t t, int64_t* row_chosen)
                            (const i64*)c->itmp, c->row_offset, c->ctail);
         comm_allgather(c, c->ctail, 2, c->cand);
         std::vector<double> cand((size_t)2 * m->world);
-        HIPCHK(c, hipMemcpyAsync(cand.data(), c->cand, cand.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // the peers go on to the broadcast below: a failure here must not just return (comm_abort)
+        hipError_t he = hipMemcpyAsync(cand.data(), c->cand, cand.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) return comm_abort(c, "reading the reset candidates", he);
         int win = 0;
         for (int r = 1; r < m->world; ++r)
             if (cand[2 * r] > cand[2 * win] || (cand[2 * r] == cand[2 * win] && cand[2 * r + 1] < cand[2 * win + 1])) win = r;
@@ -2267,7 +2304,7 @@ rri_status rri_update_T_row(rri_ctx* c, int32_t t) {
     c->run_total = 1;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
-    if (c->explicit_resid) enqueue_rT_half(c, 0, t, true);
+    if (resid_sched(c)) enqueue_rT_half(c, 0, t, true);
     else enqueue_T_half(c, 0, t, true);
     DevState s;
     r = read_state(c, &s);
@@ -2286,7 +2323,7 @@ rri_status rri_update_W_col(rri_ctx* c, int32_t t) {
     r = clear_halt(c);
     if (r != RRI_OK) return r;
     c->skip_row_finish = true;   // a lone W half: the T-row checks belong to rri_update_T_row
-    if (c->explicit_resid) enqueue_rW_half(c, 0, t);
+    if (resid_sched(c)) enqueue_rW_half(c, 0, t);
     else enqueue_W_half(c, 0, t);
     if (c->pending_wcheck) {
         wcheck_now(c, c->pending_wcheck_topic, 1, 0);
@@ -2456,29 +2493,44 @@ rri_status rri_argmax_rows(rri_ctx* c, int32_t* out_host) {
 rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, int64_t count, double lo, double hi,
                            double* out) {
     CHECK_CTX(c);
-    if (!ij || !vals || !out || count < 1) return fail(c, RRI_ERR_INVALID, "bad entry list");
+    // row-sharded (a communicator attached): collective; (i, j) are LOCAL rows, a rank may hold no entry at all, and the
+    // score is sqrt(sum over the ranks of the squared errors / sum of the counts): the same number on every rank, so
+    // the early-stop decision of nmf.py:381-407 is the same on every rank
+    if (!out || count < 0 || (count > 0 && (!ij || !vals)) || (count < 1 && !c->comm)) return fail(c, RRI_ERR_INVALID, "bad entry list");
     for (i64 e = 0; e < count; ++e)
         if (ij[2 * e] < 0 || ij[2 * e] >= c->n || ij[2 * e + 1] < 0 || ij[2 * e + 1] >= c->d)
             return fail(c, RRI_ERR_INVALID, "entry %lld out of range", e);
     HIPCHK(c, hipSetDevice(c->device));
-    i64* dij = nullptr;
-    double* dv = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dij, (size_t)count * 2 * sizeof(i64)));
-    hipError_t e = hipMalloc((void**)&dv, (size_t)count * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(dij, ij, (size_t)count * 2 * sizeof(i64), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dv, vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream);
-    double h[256];
-    if (e == hipSuccess) {
-        LK::masked_sqerr(c, dij, dv, count, lo, hi);
-        e = hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dij);
-    if (dv) (void)hipFree(dv);
-    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "masked rmse failed: %s", hipGetErrorString(e));
     double s = 0.0;
-    for (int b = 0; b < 256; ++b) s += h[b];
-    *out = std::sqrt(s / (double)count);
+    hipError_t e = hipSuccess;
+    if (count > 0) {
+        i64* dij = nullptr;
+        double* dv = nullptr;
+        e = hipMalloc((void**)&dij, (size_t)count * 2 * sizeof(i64));
+        if (e == hipSuccess) e = hipMalloc((void**)&dv, (size_t)count * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(dij, ij, (size_t)count * 2 * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dv, vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        double h[256];
+        if (e == hipSuccess) {
+            LK::masked_sqerr(c, dij, dv, count, lo, hi);
+            e = hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (dij) (void)hipFree(dij);
+        if (dv) (void)hipFree(dv);
+        if (e == hipSuccess)
+            for (int b = 0; b < 256; ++b) s += h[b];
+    }
+    double tot[2] = {s, (double)count};
+    if (c->comm) {
+        // a rank whose device work failed still takes part in the collective (its peers would wait for it otherwise) and
+        // reports its own failure afterwards
+        const rri_status r = comm_allreduce_host(c, tot, 2);
+        if (r != RRI_OK) return r;
+    }
+    if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "masked rmse failed: %s", hipGetErrorString(e));
+    if (!(tot[1] > 0.0)) return fail(c, RRI_ERR_INVALID, "no entry on any rank");
+    *out = std::sqrt(tot[0] / tot[1]);
     return RRI_OK;
 }
 

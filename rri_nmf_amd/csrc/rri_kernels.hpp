@@ -221,7 +221,6 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
                 x[u] = XV::zero();
                 if (rr < n && ok) x[u] = stream_load<NT>(reinterpret_cast<const V*>(X + (i64)rr * ldx + col));
             }
-            double ys[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rr = r + u;
@@ -249,17 +248,15 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
                     if (DO_Z) zacc[e] = fma(wv, xe[e], zacc[e]);
                 }
                 if constexpr (DO_Y && RS) wave_rowsum8_park(tile, u, lane, yp);
-                else if (DO_Y) ys[u] = wave_sum<double>(yp);
+                else if (DO_Y) {
+                    // the same six DPP steps as wave_sum, the total taken where they leave it (lane 63) and stored from there
+                    const double tot = wave_sum_lane63<double>(yp);
+                    if (lane == 63) ysh[wave * rpb + l0 + u] = tot;
+                }
             }
             if constexpr (DO_Y && RS) {
                 const double tot = wave_rowsum8_finish(tile, lane);
                 if ((lane & 7) == 0) ysh[wave * rpb + l0 + (lane >> 3)] = tot;
-            } else if (DO_Y) {
-                double yv = ys[0];
-#pragma unroll
-                for (int u = 1; u < U; ++u)
-                    if (lane == u) yv = ys[u];
-                if (lane < U) ysh[wave * rpb + l0 + lane] = yv;
             }
         }
         if (DO_Z && ok) {

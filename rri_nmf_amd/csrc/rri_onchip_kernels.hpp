@@ -184,6 +184,68 @@ __device__ __forceinline__ double onchip_simplex_theta(double v0, double v1, dou
     return theta;
 }
 
+// The same fixed point by ONE wave, the row left in LDS (LD <= 1024: 16 elements per lane, re-read in every iteration:
+// 8 KB at 128 B per clock, no registers held) -- no workgroup barrier inside the iteration.  The 8-wave form above costs
+// two barriers per iteration plus two block sums around it, ~30 barriers per projected row, on the critical path of every
+// topic step of the topic-model flags; this one needs two (before and after).  The elements are w_j = row[j] when !shifted,
+// max(row[j] - shift, 0) when shifted (the second projection of nmf.py:759-761 runs on the first one's result without
+// storing it in between).  Returns theta; *sum_all = the sum over all d elements, *sum_proj = sum_j max(w_j - theta, 0).
+// Every lane returns the same values.
+__device__ __forceinline__ double onchip_wave_theta(const double* row, int d, double s, bool shifted, double shift,
+                                                    double* sum_all, double* sum_proj, int* iters) {
+    const int lane = threadIdx.x & 63;
+    auto elem = [&](int q) -> double {
+        const int j = lane + 64 * q;
+        if (j >= d) return -1.0e300;
+        const double v = row[j];
+        return shifted ? fmax(v - shift, 0.0) : v;
+    };
+    // The iteration climbs to theta* from any lower bound and ends at the same active set, hence the same theta (the sum over
+    // that set in this lane order).  Two lower bounds are known before it starts: Michelot's own first iterate
+    // (sum of all - s) / d, and max(w) - s (the largest element alone already reaches s there).  From the larger of the two
+    // an ill-scaled row -- closed-form rows of the first sweeps sum to thousands where the simplex wants 1, three elements
+    // stay active -- needs 1-2 iterations instead of 9 (each costs ~0.4 us on this one wave: 16 LDS reads, two wave sums,
+    // a float64 division; profiles/r03_onchip_tm_sections.log).
+    double all = 0.0, vmax = -1.0e300;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double v = elem(q);
+        if (v > -1.0e299) { all += v; vmax = fmax(vmax, v); }
+    }
+    all = wave_sum<double>(all);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+    double theta = fmax((all - s) / (double)d, vmax - s);
+    i64 cnt_prev = -1;
+    int it = 1;
+    for (; it < 2 * 1024 + 2; ++it) {
+        double sum = 0.0;
+        int cnt_i = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double v = elem(q);
+            if (v > theta) { sum += v; cnt_i += 1; }
+        }
+        sum = wave_sum<double>(sum);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt_i += __shfl_xor(cnt_i, off, 64);
+        const i64 ci = (i64)cnt_i;
+        if (ci == cnt_prev || ci == 0) break;
+        theta = (sum - s) / (double)cnt_i;
+        cnt_prev = ci;
+    }
+    double sp = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double v = elem(q);
+        if (v > -1.0e299) sp += fmax(v - theta, 0.0);
+    }
+    *sum_all = all;
+    *sum_proj = wave_sum<double>(sp);
+    *iters = it;
+    return theta;
+}
+
 // DBG: sections of a topic step timed by thread 0 of workgroup 0 (a worker) and of the last workgroup (RRI_ONCHIP_TIMING,
 // tools/onchip_probe.py): 0 phase A loads, 1 phase A rest + signal, 2 wait for the workers, 3 phase B loads, 4 row dots,
 // 5 W update, 6 carry, 7 hand-over to the workers
@@ -193,7 +255,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     constexpr int NTH = ONCHIP_THREADS, NWV = ONCHIP_WAVES, CWA = ONCHIP_CWA, PG = ONCHIP_PG;
     DevState* st = a.st;
     if (st->halt) return;
-    long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long dacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long dlast = DBG ? wall_clock64() : 0;
 #define RRI_STAMP(i)                                                           \
     do {                                                                       \
@@ -445,11 +507,15 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         // among the NA workers) and finishes qf_min for the whole row itself -- Michelot's fixed point for the
                         // simplex projection, or the one-hot row -- and the checks of _project_and_check_reset_t
                         // (nmf.py:751-769), exactly as k_trow_final does; all workers come to the same row and verdict
+                        RRI_STAMP(8);                          // closed form of the own columns
                         epoch += 1u;
                         onchip_signal(flagA + b, epoch);
+                        RRI_STAMP(9);                          // slice published
                         if (onchip_wait(a.bar, flagA, NA, epoch, a.spin_limit) == 2) goto sync_failed;
+                        RRI_STAMP(10);                         // the other workers' slices are there
                         for (int j = tid; j < a.LD; j += NTH) rowsh[j] = j < a.d ? ld_agent(a.xraw + (unsigned)j) : 0.0;
                         __syncthreads();
+                        RRI_STAMP(11);                         // the whole row in LDS
                         double nx = 1.0, sumT = 0.0;
                         int iters = 0;
                         if (mode == 2) {
@@ -470,34 +536,48 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             }
                             __syncthreads();
                             for (int j = tid; j < a.d; j += NTH) rowsh[j] = (j == bi) ? 1.0 : 0.0;
+                            sumT = 1.0;                       // the unit vector: nothing to re-project, no reset
                         } else {
-                            // LD <= 1024: the row sits two elements per thread in registers from here on
-                            double v0 = tid < a.d ? rowsh[tid] : -1.0e300, v1 = tid + NTH < a.d ? rowsh[tid + NTH] : -1.0e300;
-                            double ps = (tid < a.d ? v0 : 0.0) + (tid + NTH < a.d ? v1 : 0.0);
-                            ps = block_sum(ps, scratch);
-                            nx = ps;
-                            const double th = onchip_simplex_theta(v0, v1, p.t_row_sum, scratch, &iters);
-                            if (tid < a.d) rowsh[tid] = fmax(v0 - th, 0.0);
-                            if (tid + NTH < a.d) rowsh[tid + NTH] = fmax(v1 - th, 0.0);
-                            if (b == 0 && tid == 0) st->theta = th;
-                        }
-                        __syncthreads();
-                        const double w0 = tid < a.d ? rowsh[tid] : -1.0e300, w1 = tid + NTH < a.d ? rowsh[tid + NTH] : -1.0e300;
-                        sumT = (tid < a.d ? w0 : 0.0) + (tid + NTH < a.d ? w1 : 0.0);
-                        sumT = block_sum(sumT, scratch);
-                        if (sumT > 1e-10 || p.reset_method == RESET_NONE) {
-                            if (p.t_row_sum != 0.0 && fabs(sumT - p.t_row_sum) > 1e-15) {     // nmf.py:759-761: project again
-                                int it2 = 0;
-                                const double th = onchip_simplex_theta(w0, w1, p.t_row_sum, scratch, &it2);
-                                if (tid < a.d) rowsh[tid] = fmax(w0 - th, 0.0);
-                                if (tid + NTH < a.d) rowsh[tid + NTH] = fmax(w1 - th, 0.0);
-                                iters += it2;
+                            // wave 0 alone runs both fixed points on the row in LDS (onchip_wave_theta) and leaves
+                            // {theta1, theta2, second projection taken, sum of the row, sum after the first projection,
+                            // iterations} in scratch; everybody applies them.  Two barriers instead of ~30 per row.
+                            if (wave == 0) {
+                                double all = 0.0, sp = 0.0, sp2 = 0.0, all2 = 0.0;
+                                int it1 = 0, it2 = 0;
+                                const double th1 = onchip_wave_theta(rowsh, a.d, p.t_row_sum, false, 0.0, &all, &sp, &it1);
+                                double th2 = 0.0, again = 0.0;
+                                if ((sp > 1e-10 || p.reset_method == RESET_NONE) && p.t_row_sum != 0.0 && fabs(sp - p.t_row_sum) > 1e-15) {
+                                    again = 1.0;                              // nmf.py:759-761: project again
+                                    th2 = onchip_wave_theta(rowsh, a.d, p.t_row_sum, true, th1, &all2, &sp2, &it2);
+                                }
+                                if (lane == 0) {
+                                    scratch[0] = th1; scratch[1] = th2; scratch[2] = again; scratch[3] = all; scratch[4] = sp;
+                                    scratch[5] = (double)(it1 + it2);
+                                }
                             }
-                        } else if (p.resets_left > 0) {
-                            code = HALT_EVENT_RESET_T;
-                            halt_bit = 0x80000000u;
+                            __syncthreads();
+                            const double th1 = scratch[0], th2 = scratch[1];
+                            const bool again = scratch[2] != 0.0;
+                            nx = scratch[3];
+                            sumT = scratch[4];
+                            iters = (int)scratch[5];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int j = tid + NTH * q;
+                                if (j < a.d) {
+                                    double w = fmax(rowsh[j] - th1, 0.0);
+                                    if (again) w = fmax(w - th2, 0.0);
+                                    rowsh[j] = w;
+                                }
+                            }
+                            if (b == 0 && tid == 0) st->theta = th1;
+                            if (!(sumT > 1e-10 || p.reset_method == RESET_NONE) && p.resets_left > 0) {
+                                code = HALT_EVENT_RESET_T;
+                                halt_bit = 0x80000000u;
+                            }
                         }
                         __syncthreads();
+                        RRI_STAMP(12);                         // projected
                         if (b == 0 && tid == 0) {
                             st->nt1 = nx; st->sumT = sumT; st->proj_iters = iters;
                             if (code != 0) { st->halt = code; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t; }
@@ -651,7 +731,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     }
     RRI_STAMP(7);
     if (DBG && a.dbg && tid == 0 && (b == 0 || b == G - 1))
-        for (int i = 0; i < 8; ++i) a.dbg[(b == 0 ? 0 : 16) + i] = dacc[i];
+        for (int i = 0; i < 14; ++i) a.dbg[(b == 0 ? 0 : 16) + i] = dacc[i];
     // the column check of the last W update of the call (position of the next step: sweep s_end, topic 0): workgroup 0 is
     // a worker and has waited for every workgroup's partials
     if (chk && b == 0) {

@@ -124,8 +124,13 @@ __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work
             for (int u = 0; u < UNR; ++u) {
                 const i64 qq = q + (i64)u * LPS;
                 if (qq < q1) {
+#ifdef RRI_SP_MEM      /* experiments (tools/sp_mem_ab.sh): bit 0 non-temporal value loads, bit 1 offset loads, bit 2 stores */
+                    g[u] = (RRI_SP_MEM & 2) ? __builtin_nontemporal_load(idx4 + qq) : idx4[qq];
+                    e[u] = (RRI_SP_MEM & 1) ? __builtin_nontemporal_load(val4 + qq) : val4[qq];
+#else
                     g[u] = idx4[qq];
                     e[u] = val4[qq];
+#endif
                 } else {
                     const unsigned short z = (unsigned short)bw;
                     g[u] = sp_us4{z, z, z, z};
@@ -161,7 +166,11 @@ __global__ __launch_bounds__(1024) void k_sp_blk(const SpWork* __restrict__ work
                         s2 = fma(v, v, s2);
                     }
                 }
+#ifdef RRI_SP_MEM
+                if (WRITE) { if (RRI_SP_MEM & 4) __builtin_nontemporal_store(out, val4 + qq); else val4[qq] = out; }
+#else
                 if (WRITE) val4[qq] = out;
+#endif
             }
         }
         if (DO_S) {

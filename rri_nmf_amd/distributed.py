@@ -45,7 +45,7 @@ class RowGroup(object):
     and group and attached to as many handles as wanted, one after the other."""
 
     def __init__(self, comm, rank, world, sizes, keep=()):
-        self._comm, self.rank, self.world = comm, int(rank), int(world)
+        self._comm_handle, self._parent, self.rank, self.world = comm, None, int(rank), int(world)
         self.sizes = [int(v) for v in sizes]
         self.row_lo = int(sum(self.sizes[:self.rank]))
         self.n_local = self.sizes[self.rank]
@@ -141,20 +141,44 @@ class RowGroup(object):
         dist.all_gather_object(sizes, int(n_local), group=group)
         return cls(comm, rank, world, sizes, keep=cbs)
 
+    @property
+    def _comm(self):
+        """the library's communicator, or None once the group that OWNS it has been closed: a view made by resized() looks it
+        up in its owner every time, so a view of a closed group is closed too (it used to keep a copy of the raw pointer: a
+        use-after-free at the next attach)"""
+        return self._parent._comm if self._parent is not None else self._comm_handle
+
+    @property
+    def closed(self):
+        c = self._comm
+        return c is None or not c
+
     def resized(self, sizes):
         """the same communicator for another problem: `sizes[r]` rows on rank r (the caller makes sure every rank passes
         the same list).  The view does not own the communicator: close the group it came from."""
-        view = RowGroup(self._comm, self.rank, self.world, sizes, keep=self._keep)
-        view._owner = False
+        view = RowGroup(None, self.rank, self.world, sizes, keep=self._keep)
+        view._parent = self if self._parent is None else self._parent
         return view
 
+    def gather(self, values, device=0):
+        """every rank's `values` (a short float64 vector, the same length everywhere) as a world x len array on every rank:
+        a sum over one-hot rows through the communicator (a scratch handle of one row per rank carries the call)"""
+        from .engine import RRIEngine
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64)).ravel()
+        buf = np.zeros((self.world, v.size))
+        buf[self.rank] = v
+        with RRIEngine(1, 1, 1, dtype=np.float64, device=device) as eng:
+            eng.attach_group(self.resized([1] * self.world))
+            out = eng.comm_sum(buf.ravel())
+        return np.asarray(out).reshape(self.world, v.size)
+
     def close(self):
-        if not getattr(self, '_owner', True):
+        if self._parent is not None:
             return
-        if self._comm is not None and self._comm:
+        if self._comm_handle is not None and self._comm_handle:
             from . import _capi
-            _capi.load_library().rri_comm_destroy(self._comm)
-            self._comm = None
+            _capi.load_library().rri_comm_destroy(self._comm_handle)
+            self._comm_handle = None
 
     def __enter__(self):
         return self

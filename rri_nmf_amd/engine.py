@@ -108,6 +108,9 @@ class RRIEngine(object):
             self._check(self._lib.rri_attach_comm(self._h, None, 0, 0))
             self.group = None
             return
+        if group.closed:
+            # NULL would DETACH (rri_attach_comm): a later objective() would silently be this rank's share only
+            raise ValueError('the RowGroup has been closed: a group must outlive every handle and obj_calculator that uses it')
         if group.n_local != self.n:
             raise ValueError('the group registered %d rows for this rank, the handle has %d' % (group.n_local, self.n))
         self._check(self._lib.rri_attach_comm(self._h, group._comm, group.row_lo, group.n_global))
@@ -359,7 +362,8 @@ class RRIEngine(object):
         return out
 
     def masked_rmse(self, I, J, vals, lo, hi):
-        ij = np.ascontiguousarray(np.stack([np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64)], 1))
+        """clipped RMSE of W T on the listed entries; row-sharded: local rows, collective, the global score on every rank"""
+        ij = np.ascontiguousarray(np.stack([np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64)], 1).reshape(-1, 2))
         v = np.ascontiguousarray(np.asarray(vals, dtype=np.float64))
         out = C.c_double(0.0)
         self._check(self._lib.rri_masked_rmse(self._h, ij.ctypes.data_as(C.POINTER(C.c_int64)),

@@ -379,10 +379,13 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         # per-row weights with their refit) or that decides per rank (callbacks) is not part of the sharded call
         if (_is_empty(W_in) or _is_empty(T_in)) and W_mat is not None:
             raise ValueError('a row-sharded weighted call needs W_in (this rank\'s rows) and T_in')
-        if w_row is not None or preprocess is not None or store_gradients or (eps_gauss_t and delta_gauss_t) or \
-                callable(early_stop):
+        # an early_stop callback that carries `device_entries` (what NMF_RS_Estimator.fit installs: the clipped RMSE on its
+        # held-out entries, sklearn_interface.py:71-93) is scored by the library over ALL ranks' entries, so every rank takes
+        # the same decision (nmf.py:381-407); a callback that wants W, T on the host would see one rank's rows
+        host_stop = callable(early_stop) and getattr(early_stop, 'device_entries', None) is None
+        if w_row is not None or preprocess is not None or store_gradients or (eps_gauss_t and delta_gauss_t) or host_stop:
             raise NotImplementedError('w_row, preprocess, store_gradients, the Gaussian mechanism and early_stop callbacks '
-                                      'are single-handle options')
+                                      'that need W, T on the host are single-handle options')
     draw_noise = None
     if eps_gauss_t and delta_gauss_t and not fix_T:
         # Gaussian mechanism on the T-row sums (nmf.py:422-435; Dwork & Roth p. 261)
@@ -464,8 +467,10 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         raise ValueError('W_in has wrong dimensions, must be n*k')
     if not _is_empty(T_in) and np.shape(T_in) != (k, d):
         raise ValueError('T_in has wrong dimensions, must be k*d')
-    if schedule == 'residual' and (W_mat is not None or fix_W or fix_T or k < 2):
-        raise NotImplementedError("schedule='residual' is the unweighted flavour with both halves free and k >= 2")
+    if schedule == 'residual' and W_mat is not None:
+        raise NotImplementedError("schedule='residual' belongs to the unweighted flavour (the weighted one always keeps its masked residual)")
+    # fix_W / fix_T / k = 1 on a handle of the explicit-residual schedule: one half of every step is missing, and the library
+    # steps such calls in the Gram form (T fixed: X T^T once, no pass over the matrix per topic) -- fold-in works on either handle
     eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern, schedule)
     try:
         if group is not None:

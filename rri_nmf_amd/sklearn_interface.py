@@ -81,6 +81,12 @@ class NMF_RS_Estimator(_FactorPair, sklearn.base.BaseEstimator):
         """X: (m, 2) index pairs (i, j); y: the m observed values X[i, j]."""
         X, y = check_X_y(X, y)
         self.min_rating, self.max_rating = np.min(y), np.max(y)
+        grp = self.nmf_kwargs.get('group')
+        if grp is not None:
+            # row-sharded fit (one rank's rows, LOCAL row indices in X): the clip bounds of predictions and of the early-stop
+            # score are those of ALL ratings, so that every rank scores and stops alike
+            mm = grp.gather([self.min_rating, self.max_rating], device=self.nmf_kwargs.get('device', 0))
+            self.min_rating, self.max_rating = mm[:, 0].min(), mm[:, 1].max()
         shape = (self.n, self.d)
         if self.use_validation_early_stopping:
             ij_tr, ij_val, r_tr, r_val = train_test_split(X, y, test_size=0.05, random_state=0,

@@ -53,6 +53,13 @@ GROUP_CASES = {
     'residual_schedule_f64': (1501, 700, 6, 3, False, 'float64', dict(schedule='residual')),
     'residual_schedule_f32_tm': (2600, 1200, 7, 3, False, 'float32', dict(schedule='residual', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
     'residual_schedule_resets_W': (600, 200, 4, 2, False, 'float64', dict(schedule='residual', t_row_sum=1.0, reg_w_l1=1e6)),
+    # fixed halves asked of the explicit-residual schedule (the estimators' transform with nmf_kwargs={'schedule': 'residual'}):
+    # the library steps them in the Gram form on that handle
+    'residual_schedule_fold_in': (1000, 400, 5, 4, False, 'float64', dict(schedule='residual', fix_T=True, t_row_sum=1.0, w_row_sum=1.0)),
+    # early stopping on held-out entries scored on the device (what NMF_RS_Estimator.fit installs by default,
+    # sklearn_interface.py:71-93, nmf.py:381-407): every rank scores ITS rows' entries, the score is all-reduced
+    'weighted_early_stop': (1201, 515, 5, 14, True, 'float64', dict(t_row_sum=1.0, reset_topic_method=None, _early_stop=True)),
+    'pattern_only_early_stop': (1201, 515, 5, 14, 'sparse', 'float32', dict(t_row_sum=1.0, reset_topic_method=None, _early_stop=True)),
     'c4_proportions_unequal': (100003, 1000, 50, 1, False, 'float32', dict()),
     # no W_in / T_in: the start itself is computed row-sharded (initialization.randomized_svd_sharded and friends)
     'start_nndsvd': (1501, 700, 6, 3, False, 'float64', dict(_init='nndsvd', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
@@ -70,7 +77,19 @@ def nmf_inputs(name):
     X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
     init = flags.pop('_init', None)
     keep_T = flags.pop('_T_in', False)
+    held_out = None
+    if flags.pop('_early_stop', False):
+        # 5 % of the observed entries are held out of the fit (mask 0 there) and scored after every sweep
+        rs = np.random.RandomState(7)
+        ii, jj = np.nonzero(M)
+        pick = rs.rand(ii.size) < 0.05
+        held_out = (ii[pick], jj[pick], np.asarray(X[ii[pick], jj[pick]], dtype=np.float64), 0.0, float(X.max()))
+        M = M.copy()
+        M[ii[pick], jj[pick]] = 0
+        X = X * M
     kw = dict(max_iter=sweeps, eps_stop=-1, compute_obj_each_iter=True, dtype=np.dtype(store), **flags)
+    if held_out is not None:
+        kw['early_stop'] = held_out_score(held_out, 0, n)
     if init is not None:       # the start comes from initialize_nmf (the fold-in case keeps T_in, as the estimators' transform does)
         kw.update(init=init, random_state=0, device_init=True)
         W0 = []
@@ -81,6 +100,21 @@ def nmf_inputs(name):
         A.data = np.asarray(X[M > 0], dtype=np.float64)
         return A, sp.csr_matrix(M), W0, T0, k, kw
     return X, M, W0, T0, k, kw
+
+
+def held_out_score(entries, lo, hi):
+    """an early_stop callback for nmf(): the clipped RMSE on the held-out entries of rows [lo, hi), local row indices, carried
+    as `device_entries` so that the library scores them (collectively when the call is row-sharded)"""
+    vi, vj, vr, clip_lo, clip_hi = entries
+    keep = (vi >= lo) & (vi < hi)
+
+    def score(X_ignored, W, T):
+        pred = np.clip(np.einsum('ij,ji->i', W[vi[keep] - lo, :], T[:, vj[keep]]), clip_lo, clip_hi)
+        return np.sqrt(np.mean((pred - vr[keep]) ** 2))
+
+    score.device_entries = (vi[keep] - lo, vj[keep], vr[keep], clip_lo, clip_hi)
+    score.all_entries = entries
+    return score
 
 
 def _init_pg(backend, **kw):
@@ -106,6 +140,8 @@ def case_group_host_transport(out, name):
         lo, hi = cut[rank], cut[rank + 1]
         if rank == 1 and world == 2 and os.environ.get('RRI_TEST_SEED_OTHER_RANK'):
             np.random.seed(12345)         # only rank 0's generator may matter for 'random' resets
+        if callable(kw.get('early_stop')):
+            kw['early_stop'] = held_out_score(kw['early_stop'].all_entries, lo, hi)      # this rank's rows, local indices
         with RowGroup.over_torch(hi - lo) as grp:
             assert (grp.row_lo, grp.n_global) == (lo, n)
             r = nmf_mod.nmf(X[lo:hi], k, W_mat=None if M is None else M[lo:hi], W_in=W0[lo:hi] if len(W0) else [], T_in=T0, group=grp, **kw)
@@ -138,6 +174,42 @@ def case_group_estimator(out):
             W5, T5 = E.W.copy(), E.T.copy()
             E.one_iter(X[lo:hi])
         np.savez(out, W=W5, T=T5, W6=E.W, T6=E.T, obj=np.array(E.nmf_outputs['obj_history']), lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+def rs_estimator_problem():
+    """ratings on a 5-star scale: (index pairs, values, start) of a 900 x 260 problem, 20 % observed"""
+    rs = np.random.RandomState(11)
+    n, d, k = 900, 260, 4
+    Wt, Tt = rs.rand(n, k), rs.rand(k, d)
+    R = np.clip(np.round(1 + 4 * (Wt @ Tt) / (Wt @ Tt).max()), 1, 5)
+    obs = rs.rand(n, d) < 0.2
+    ii, jj = np.nonzero(obs)
+    W0, T0 = 0.5 * rs.rand(n, k), rs.rand(k, d)
+    return np.column_stack((ii, jj)), R[ii, jj], W0, T0, (n, d, k)
+
+
+def case_group_rs_estimator(out):
+    """NMF_RS_Estimator.fit with its DEFAULTS (early stopping on a 5 % hold-out, sklearn_interface.py:71-123) on a row block:
+    nmf_kwargs={'group': ...}, warm start given (the weighted start is not computed row-sharded)"""
+    import torch.distributed as dist
+    from rri_nmf_amd import sklearn_interface as si
+    from rri_nmf_amd.distributed import RowGroup
+    rank, world = _init_pg('gloo')
+    try:
+        ij, y, W0, T0, (n, d, k) = rs_estimator_problem()
+        lo, hi = (0, 520) if rank == 0 else (520, n)
+        mine = (ij[:, 0] >= lo) & (ij[:, 0] < hi)
+        if rank == 1:
+            y = y.copy()
+            y[mine & (y == 1)] = 2          # the lowest rating occurs on rank 0 only: the clip bounds must still be the global ones
+        with RowGroup.over_torch(hi - lo) as grp:
+            E = si.NMF_RS_Estimator(hi - lo, d, k, W=W0[lo:hi], T=T0, max_iter=12, nmf_kwargs={'group': grp, 'dtype': np.float64})
+            E.fit(np.column_stack((ij[mine, 0] - lo, ij[mine, 1])), y[mine])
+            score = E.score(np.column_stack((ij[mine, 0] - lo, ij[mine, 1])), y[mine])
+        np.savez(out, W=E.W, T=E.T, obj=np.array(E.nmf_outputs['obj_history']), lo=lo, hi=hi, clip=np.array([E.min_rating, E.max_rating]),
+                 score=score)
     finally:
         dist.destroy_process_group()
 

@@ -208,3 +208,54 @@ def test_weighted_dense_and_pattern_only_paths_agree_at_full_size(problem):
         o = res[name][2]
         assert all(b <= a for a, b in zip(o, o[1:])), (name, o)
         assert res[name][0].min() >= 0 and res[name][1].min() >= 0 and res[name][1].max() <= 1.0 + 1e-12
+
+
+# bounds of test_c5_slice_against_the_cpu_oracle: (objective, masked reconstruction M .* (W T), W, T), relative
+C5_SLICE_BOUNDS = {'dense64': (1e-9, 1e-7, 1e-6, 1e-6), 'sparse64': (1e-9, 1e-7, 1e-6, 1e-6),
+                   'dense32': (1e-5, 2e-3, None, None), 'sparse32': (1e-5, 2e-3, None, None)}
+
+
+def test_c5_slice_against_the_cpu_oracle(problem):
+    """C5 against the CPU ORACLE (the reference's operation order: two n d k GEMMs per topic, nmf.py:687-701, 735-746), not
+    against another of the build's handles: the first 20000 rows of the full-size problem -- same X, same 5 % mask, same
+    start -- as a problem of its own, ONE sweep (about a CPU minute: a full-size sweep of the oracle takes five).  All four
+    device handles (dense bit-packed / pattern-only x float64 / fp32 residual): objective and masked reconstruction at
+    stated bounds; W, T for the float64-storage ones (an fp32 residual leaves the trajectory of W, T its own rounding
+    amplification: DESIGN 7)."""
+    import scipy.sparse as sp
+    import torch
+    from oracle import rri_oracle as orc
+    from rri_nmf_amd.engine import RRIEngine
+    X, W0, T0 = problem
+    rows = 20000
+    g = torch.Generator(device=X.device)
+    g.manual_seed(2)
+    Mask = (torch.rand(N, D, device=X.device, generator=g) < 0.05)[:rows].clone()        # the mask of the full-size test, its first rows
+    Xs = X[:rows]
+    M64 = Mask.cpu().numpy().astype(np.float64)
+    X64 = Xs.cpu().numpy().astype(np.float64) * M64
+    W0h, T0h = W0[:rows].cpu().numpy(), T0.cpu().numpy()
+    flags = dict(t_row_sum=1.0, reset_topic_method=None)
+    ref = orc.nmf(X64, K, W_mat=M64, W_in=W0h.copy(), T_in=T0h.copy(), max_iter=1, eps_stop=-1, compute_obj_each_iter=True, **flags)
+    ref_rec = M64 * (ref['W'] @ ref['T'])
+    ref_obj = ref['obj_history'][-1]
+    Pm = sp.csr_matrix(M64)
+    A = sp.csr_matrix((X64[M64 > 0], Pm.indices, Pm.indptr), shape=X64.shape)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    out = {}
+    for name, dtype, weighted in (('dense64', np.float64, True), ('sparse64', np.float64, 'sparse'),
+                                  ('dense32', np.float32, True), ('sparse32', np.float32, 'sparse')):
+        with RRIEngine(rows, D, K, dtype=dtype, weighted=weighted) as e:
+            if weighted == 'sparse':
+                e.upload_observed_csr(A)
+            else:
+                e.upload_X(X64.astype(dtype)); e.upload_mask(M64.astype(dtype))
+            e.set_W(W0h); e.set_T(T0h); e.set_params(**flags)
+            e.sweep(1)
+            W, T, o = e.get_W(), e.get_T(), e.objective()
+        out[name] = (abs(o / ref_obj - 1.0), rel(M64 * (W @ T), ref_rec), rel(W, ref['W']), rel(T, ref['T']))
+    print('C5, first %d rows as a problem, one sweep, against the CPU oracle (objective, M.*WT, W, T):' % rows,
+          {k: tuple('%.1e' % v for v in vals) for k, vals in out.items()})
+    for name, got in out.items():
+        for what, v, bound in zip(('objective', 'masked reconstruction', 'W', 'T'), got, C5_SLICE_BOUNDS[name]):
+            assert bound is None or v < bound, (name, what, v, bound)

@@ -197,9 +197,26 @@ def test_residual_schedule_ragged_shapes_and_resumability():
         Wh, Th = e.get_W(), e.get_T()
     Ws, Ts, _ = run_residual(X, W0, T0, 1, np.float64)
     assert relfro(Wh, Ws) < 1e-10 and relfro(Th, Ts) < 1e-10
-    with pytest.raises(NotImplementedError):
-        with engine(50, 40, 3, schedule='residual') as e:
-            e.set_params(fix_T=True)
+    # fixed halves on a handle of this schedule: one half of every step is missing, the library steps such calls in the Gram
+    # form (T fixed: X T^T once, no pass per topic) -- bit for bit what a Gram-form handle gives; switching back and forth
+    # on ONE handle keeps no sums of the other form
+    for fixed in (dict(fix_T=True), dict(fix_W=True)):
+        out = []
+        for schedule in ('residual', 'gram'):
+            with engine(700, 333, 6, dtype=np.float64, schedule=schedule) as e:
+                e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+                e.sweep(2)                               # both halves free (the residual handle: its own schedule)
+                e.set_params(**fixed)
+                e.sweep(2)
+                mid = (e.get_W(), e.get_T())
+                e.set_params()
+                e.sweep(1)
+                out.append(mid + (e.get_W(), e.get_T(), e.objective()))
+        a, b = out
+        assert relfro(a[0], b[0]) < 1e-9 and relfro(a[1], b[1]) < 1e-9, fixed
+        assert relfro(a[2], b[2]) < 1e-9 and relfro(a[3], b[3]) < 1e-9 and abs(a[4] - b[4]) <= 1e-9 * abs(b[4])
+        if 'fix_T' in fixed:
+            assert np.array_equal(a[1], out[0][1])
 
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
@@ -244,5 +261,10 @@ def test_nmf_with_the_residual_schedule_on_the_text_fixture():
                         w_row_sum=1.0, project_W_each_iter=False, dtype=dtype, schedule='residual')
         assert relfro(r['W'], g['W_s10']) < (2e-9 if dtype == np.float64 else 1e-4)
         assert np.array_equal(np.argmax(r['W'], 1), g['argmax_s10'])
-    with pytest.raises(NotImplementedError):
-        nmf_mod.nmf(X, 5, W_in=W0, T_in=T0, max_iter=1, fix_T=True, schedule='residual')
+    # fold-in through the estimator (NMF_TM_Estimator.transform: fix_T, max_iter = 4, sklearn_interface.py:327-333) with the
+    # explicit-residual schedule requested for every call: the reference's held-out vectors of G1
+    from rri_nmf_amd import sklearn_interface as si
+    n, d = X.shape
+    M = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=10, nmf_kwargs={'eps_stop': -1, 'schedule': 'residual'}).fit(X)
+    Wte = M.transform(g['Xte'])
+    assert relfro(Wte, g['Wte']) < 1e-7 and np.array_equal(np.argmax(Wte, 1), g['argmax_te'])

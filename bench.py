@@ -53,6 +53,9 @@ CONFIGS = {
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PROFILE_ROUND = 'r03'
+# rows of the weighted workloads the CPU oracle runs (one sweep: about a CPU-minute on 16 threads; a full-size sweep of the
+# reference's two n*d*k GEMMs per topic takes five) -- the same slice tests/test_full_size_gpu.py::test_c5_slice_against_the_cpu_oracle asserts
+WEIGHTED_CPU_ROWS = 20000
 
 
 def parse():
@@ -344,7 +347,7 @@ def main():
         t_up = time.perf_counter()
         eng.upload_observed_csr(A)
         t_up = time.perf_counter() - t_up
-        Xs_keep, Ms_keep = X[:2000].cpu().numpy().astype(np.float64), Mask[:2000].cpu().numpy().astype(np.float64)
+        Xs_keep, Ms_keep = X[:WEIGHTED_CPU_ROWS].cpu().numpy().astype(np.float64), Mask[:WEIGHTED_CPU_ROWS].cpu().numpy().astype(np.float64)
         del X, Mask, A
         torch.cuda.empty_cache()
     else:
@@ -524,7 +527,7 @@ def main():
 
     thr = int(min(16, os.cpu_count() or 16))       # the box's CPU share for one GPU
     if rank == 0 and world == 1 and weighted and not args.no_cpu_baseline:
-        rows = min(2000, n_local)
+        rows = min(WEIGHTED_CPU_ROWS, n_local)
         if sparse:
             Xs, Ms = Xs_keep[:rows], Ms_keep[:rows]
         else:
@@ -557,10 +560,11 @@ def main():
                                 'relfro_W': relfro(Wg, ref['W']), 'relfro_T': relfro(Tg, ref['T']),
                                 'relfro_masked_WT': relfro(rec(Wg, Tg), rec(ref['W'], ref['T'])),
                                 'rel_objective': abs(og - ref['obj_history'][-1]) / abs(ref['obj_history'][-1]),
-                                'statement': 'the residual is stored in %s: parity of this flavour is stated on the objective and the '
-                                             'masked reconstruction M.(WT) (at full size from a random start the trajectory of W, T '
-                                             'amplifies a storage rounding of 6e-8 to percents while those two agree: '
-                                             'tests/test_full_size_gpu.py, DESIGN.md 7)' % args.storage}
+                                'statement': 'the first %d rows of the workload -- same X, mask and start -- as a problem of its own, one '
+                                             'sweep, against the CPU oracle (the reference\'s operation order).  The residual is stored in '
+                                             '%s; at the FULL size the first sweep from this random start amplifies a storage rounding '
+                                             'of 6e-8 to percents in W, T while objective and masked reconstruction M.(WT) agree '
+                                             '(tests/test_full_size_gpu.py, DESIGN.md 7)' % (rows, args.storage)}
         out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
     if rank == 0 and world == 1 and not weighted:
         # the explicit rank-one residual update R <- R - a b^T (read + write, fused residual products), with the handle's

@@ -1163,26 +1163,42 @@ void w_reduce(rri_ctx* c) {
                        (const double*)nullptr, 0, c->k, c->red + c->LD, (const DevState*)c->st);
 }
 
+// few row blocks of partial column sums, one device: the column verdict, both reductions and the closed form of the T row are
+// ONE launch (k_wtrow_small)
+bool wtrow_small(const rri_ctx* c) { return !c->comm && c->nrb <= 64; }
+
 // column sums (a, nw) of topic t over the current E into red[0 .. 2 LD)
-void enqueue_wT_sums(rri_ctx* c, int t) {
+// `fused`: the caller goes straight on to enqueue_wT_solve(..., fused) -- rri_sweep does; the split stepping of
+// rri_topic_reduce_local / rri_topic_finish, where the host reads (and may rewrite) red in between, does not
+void enqueue_wT_sums(rri_ctx* c, int t, bool fused = false) {
     const double* wt_t = c->W + (i64)t * c->ldw;
     if (!c->carry_valid || c->carry_topic != t)
         DISPATCH(c, (L::template wpass<false, true, false, false>(c, nullptr, wt_t, c->zeros, c->zeros, nullptr, nullptr)));
+    if (fused) return;       // reduced inside k_wtrow_small
     TimedScope ts(c, 2);
     w_reduce(c);
 }
 
 // T row from red (local sums, or all-reduced ones on the row-sharded path)
-void enqueue_wT_solve(rri_ctx* c, int sweep, int t) {
+void enqueue_wT_solve(rri_ctx* c, int sweep, int t, bool fused = false) {
     const double* wt_t = c->W + (i64)t * c->ldw;
     {
         TimedScope ts(c, 2);
+        const int nb_small = (int)((c->LD + 127) / 128);
+        if (fused) {
+            const int nb = nb_small;
+            hipLaunchKernelGGL(k_wtrow_small, dim3(nb), dim3(128), 0, c->stream, (const double*)c->T, c->LD, (int)c->d, t,
+                               (const double*)c->Zpart, (const double*)c->Z2part, c->LD, c->nrb, (const double*)c->Gpart,
+                               c->nwb256, c->k, c->pending_wcheck ? 1 : 0, c->pending_wcheck_topic, sweep, c->red, c->xraw,
+                               c->tpart, c->tpart_idx, kparams(c), c->st);
+            c->pending_wcheck = false;
+        } else
         hipLaunchKernelGGL(k_wtrow, dim3(c->ntb), dim3(128), 0, c->stream, (const double*)c->T, c->LD, (int)c->d, t,
                            (const double*)c->red, c->LD, c->xraw, c->tpart, c->tpart_idx, kparams(c),
                            (const DevState*)c->st);
         const int scale_w = (c->prm.fix_W && no_regs(c)) ? 1 : 0;
         hipLaunchKernelGGL(k_wtrow_final, dim3(1), dim3(1024), 0, c->stream, c->T, c->LD, (int)c->d, t, c->xraw,
-                           (const double*)c->tpart, (const i64*)c->tpart_idx, c->ntb, c->dtv, scale_w, sweep,
+                           (const double*)c->tpart, (const i64*)c->tpart_idx, fused ? nb_small : c->ntb, c->dtv, scale_w, sweep,
                            kparams(c), c->st);
     }
     c->carry_valid = false;
@@ -1200,7 +1216,8 @@ void enqueue_wT_solve(rri_ctx* c, int sweep, int t) {
 }
 
 void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
-    enqueue_wT_sums(c, t);
+    const bool fused = wtrow_small(c);
+    enqueue_wT_sums(c, t, fused);
     if (c->comm) {
         // row-sharded: red = [numerator | denominator | sum of the last updated column, its negative-denominator flag]
         // is all-reduced; the pending column verdict is taken from the reduced tail (option A)
@@ -1216,7 +1233,7 @@ void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
                                sweep, t, kparams(c), c->st);
         c->pending_wcheck = false;
     }
-    enqueue_wT_solve(c, sweep, t);
+    enqueue_wT_solve(c, sweep, t, fused);
 }
 
 void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
@@ -1282,7 +1299,9 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
                 // once per sweep (and after resets), unless rri_objective has just rebuilt it from the same W, T
                 if (!c->resid_valid || (t == 0 && ph == 0 && !c->resid_fresh)) w_refresh(c);
                 if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, sa, t);
-                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t, c->comm != nullptr && !c->prm.fix_T);
+                // the column verdict rides on the next T-row step where that step can take it: row-sharded (the all-reduce), or one
+                // device with few row blocks (k_wtrow_small)
+                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t, (c->comm != nullptr || wtrow_small(c)) && !c->prm.fix_T);
             }
         }
         return;

@@ -290,6 +290,56 @@ __global__ __launch_bounds__(128) void k_wtrow(const double* __restrict__ T, i64
     if (tid == 0) { tpart[blockIdx.x] = s; flags[blockIdx.x] = ng > 0.0 ? 1 : 0; }
 }
 
+__device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int sweep, int pos, const KParams& p, DevState* st);
+
+// Where few row blocks leave partial column sums (pattern-only handles: one per 10240 rows; small dense problems), the column
+// verdict of the last W update (k_wcheck_wcol), the two reductions (k_reduce on Zpart and Z2part) and k_wtrow are ONE launch:
+// four dependent 5-us kernels per topic step become one (round 3: the six small kernels between two passes were 34 us of a
+// 260-us topic step at BASELINE config 5 on the observed pattern).  Every workgroup takes the verdict itself from the same
+// sums -- the same decision everywhere, nothing is updated when the step halts -- and leaves red = [a | nw] as k_reduce does.
+__global__ __launch_bounds__(128) void k_wtrow_small(const double* __restrict__ T, i64 ldt, int d, int t,
+                                                     const double* __restrict__ Zpart, const double* __restrict__ Z2part,
+                                                     i64 ldz, int nrb, const double* __restrict__ Gpart, int nwb, int k,
+                                                     int check_prev, int tprev, int sweep, double* __restrict__ red,
+                                                     double* __restrict__ xraw, double* __restrict__ tpart,
+                                                     i64* __restrict__ flags, KParams p, DevState* st) {
+    if (st->halt) return;
+    __shared__ double scratch[40];
+    const int tid = threadIdx.x;
+    if (check_prev) {          // nmf.py:471-476 / 793-816 for the column updated last, at the position of THIS step
+        double a = ordered_sum<8>(Gpart + k + 1, k + 2, tid, nwb, 128);
+        double f = ordered_sum<8>(Gpart + k, k + 2, tid, nwb, 128);
+        a = block_sum(a, scratch);
+        f = block_sum(f, scratch);
+        const bool unb = f > 0.0 && !p.has_wrs;
+        const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(a > 0.0);
+        if (unb || ev || err) {
+            if (blockIdx.x == 0 && tid == 0) wcol_verdict(a, f, tprev, sweep, t, p, st);
+            return;
+        }
+    }
+    const i64 j = (i64)blockIdx.x * 128 + tid;
+    double x = 0.0, neg = 0.0;
+    if (j < ldz) {
+        const double a = ordered_sum<8>(Zpart + j, ldz, 0, nrb, 1), nw = ordered_sum<8>(Z2part + j, ldz, 0, nrb, 1);
+        red[j] = a;
+        red[ldz + j] = nw;
+        if (j < d) {
+            const double tj = T[(i64)t * ldt + j];
+            const double numer = fma(tj, nw, a) - p.reg_t_l1;      // w^T Rt - reg_t_l1 (nmf.py:437)
+            const double c = nw + p.reg_t_l2;                       // nmf.py:438
+            if (c < 0.0) neg = 1.0;
+            if (c > 0.0) x = fmax(numer, 0.0) / (c + p.eps);
+            if (p.has_trs) x = fmin(x, p.t_row_sum);                // ub = t_row_sum (min(ub, s) when s is given)
+            xraw[j] = x;
+        }
+    }
+    const double s = block_sum(x, scratch);
+    const double ng = block_sum(neg, scratch);
+    if (tid == 0) { tpart[blockIdx.x] = s; flags[blockIdx.x] = ng > 0.0 ? 1 : 0; }
+}
+
 // finishes the weighted T row: unbounded check, rescale to sum s (optimization.py:85-87), the row checks of
 // _project_and_check_reset_t, T[t,:] and dt = scale_w * t_new - t_old (scale_w = nt1 when fix_W keeps and
 // rescales the column, nmf.py:450-452; 1 otherwise).

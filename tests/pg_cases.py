@@ -257,6 +257,33 @@ def case_group_rccl_single_rank(out):
         json.dump(res, f)
 
 
+def case_group_closed(out):
+    """a closed RowGroup (and a view of it) must be refused by attach_group instead of detaching the handle"""
+    from rri_nmf_amd.distributed import RowGroup
+    from rri_nmf_amd.engine import RRIEngine
+    res = {}
+    grp = RowGroup.rccl(300, device=0, exchange=lambda obj: [obj], rank=0, world=1)
+    view = grp.resized([200])
+    res['open_before'] = (not grp.closed) and (not view.closed)
+    with RRIEngine(200, 50, 3, dtype=np.float64) as e:
+        e.attach_group(view)
+        res['attached_world'] = e.comm_stats()[1]
+    grp.close()
+    res['closed_after'] = grp.closed and view.closed
+    res['refused'] = []
+    for name, g, rows in (('group', grp, 300), ('view', view, 200)):
+        with RRIEngine(rows, 50, 3, dtype=np.float64) as e:
+            try:
+                e.attach_group(g)
+            except ValueError as ex:
+                if 'closed' in str(ex):
+                    res['refused'].append(name)
+    grp.close()
+    res['idempotent'] = True
+    with open(out, 'w') as f:
+        json.dump(res, f)
+
+
 def case_legacy_protocol_single_rank_nccl(out):
     """ShardedRRI (collective in the caller's hands: torch.distributed on the engine's stream) with a one-rank RCCL
     group of torch's: the split step protocol equals rri_sweep, with and without reset events"""

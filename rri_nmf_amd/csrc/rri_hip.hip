@@ -19,6 +19,8 @@
                          // library has no link-time dependency on RCCL and loads on a box without it
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
@@ -1351,11 +1353,16 @@ bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     g->shmem = doubles * sizeof(double);
     return g->shmem <= 150 * 1024;
 }
+// A persistent launch that gave up means the device is shared with somebody whose grids collide with ours: every handle of the
+// process keeps off the persistent path until this time (steady clock, ns), so that a process that makes a handle per nmf()
+// call does not walk into the same wait again and again (tools/onchip_two_processes.py).
+std::atomic<long long> g_onchip_backoff_until{0};
+long long steady_now_ns() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // what the persistent kernel covers: the unweighted flavour, either storage type, both halves free (with or without the per-step
 // simplex projection of T), 2 <= k <= ONCHIP_MAX_K, on one device
 bool onchip_ok(const rri_ctx* c) {
     OnchipGeom g;
-    return g_onchip && !c->onchip_off && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
+    return g_onchip && !c->onchip_off && steady_now_ns() >= g_onchip_backoff_until.load() && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
            c->k <= ONCHIP_MAX_K && !c->prm.fix_W && !c->prm.fix_T && c->ldx % c->VN == 0 && ((uintptr_t)c->X) % 16 == 0 &&
            onchip_geometry(c, &g);
 }
@@ -1428,7 +1435,9 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     a.s0 = cur.sweep; a.t0 = cur.topic; a.ph0 = cur.phase; a.s_end = c->run_total;
     a.skip_row_finish = c->skip_row_finish ? 1 : 0;
     a.spin_limit = 2000000u;            // polls of ~1 us: a grid that stands still for seconds gives up (HALT_ERR_GRID_SYNC)
-    if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
+    a.entry_spin_limit = 40000u;        // the hand-over at kernel entry: a grid that is not resident as a whole shows within ~40 ms
+    if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = a.entry_spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
+    if (const char* e = getenv("RRI_ONCHIP_ENTRY_SPIN_LIMIT")) a.entry_spin_limit = (unsigned)std::max(0, atoi(e));
     a.p = kparams(c); a.st = c->st;
     a.dbg = nullptr;
     if (getenv("RRI_ONCHIP_TIMING")) {           // diagnostics: per-section ticks of the last launch, printed at the next one
@@ -2181,6 +2190,9 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
         c->onchip_in_flight = false;
         c->onchip_fallbacks += 1;
         c->onchip_off = true;
+        long long backoff_ms = 2000;                                        // the whole process: 2 s off the persistent path
+        if (const char* e = getenv("RRI_ONCHIP_BACKOFF_MS")) backoff_ms = std::max(0, atoi(e));      // tests: 0
+        g_onchip_backoff_until.store(steady_now_ns() + backoff_ms * 1000000LL);
         if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: the persistent sweep gave up; sweeps %d.. rerun launch by launch\n", from.sweep);
         HIPCHK(c, hipMemcpyAsync(c->W, c->Wsafe, (size_t)c->k * c->ldw * 8, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->T, c->Tsafe, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));

@@ -67,6 +67,7 @@ struct OnchipArgs {
     int s0, t0, ph0, s_end;        // cursor (sweep, topic, phase) and end sweep (exclusive)
     int skip_row_finish;           // a resumed W half whose T-row checks already ran (after a T-row reset)
     unsigned spin_limit;
+    unsigned entry_spin_limit;     // polls of the all-grid hand-over at kernel entry (short: a grid that is not resident as a whole shows here)
     long long* dbg;                // diagnostics build only: [2][16] accumulated 100 MHz ticks per section (workgroup 0, workgroup G-1)
     KParams p; DevState* st;
 };
@@ -409,6 +410,15 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     bool have_carry = false;
     int chk = 0, tprev = -1;
     unsigned stepq = 0;       // topic steps of this launch so far
+
+    // Entry hand-over: every workgroup reports in and waits for all others BEFORE anything is written to W, T or the partial
+    // arrays.  A grid that is not resident as a whole -- two processes' persistent grids dispatched at the same moment each
+    // hold a part of the CUs (tools/onchip_two_processes.py: 5-13 times in 400 calls with four processes on one GPU) -- fails
+    // HERE, after entry_spin_limit polls (~tens of milliseconds) instead of the seconds of the in-run bound, with nothing to
+    // undo; the host reruns the range launch by launch and backs the process off the persistent path for a while.
+    epoch += 1u;
+    onchip_signal(flagB + b, epoch);
+    if (onchip_wait(a.bar, flagB, G, epoch, a.entry_spin_limit) == 2) goto sync_failed;
     for (int s = a.s0; s < a.s_end; ++s) {
         for (int t = (s == a.s0) ? a.t0 : 0; t < k; ++t) {
             const int ph = (s == a.s0 && t == a.t0) ? a.ph0 : 0;

@@ -189,6 +189,7 @@ def test_a_grid_that_cannot_synchronise_falls_back_to_the_launch_per_phase_sched
     Wb, Tb, _, _ = run(X, W0, T0, 2, False, **flags)
     Wb5, Tb5, _, _ = run(X, W0, T0, 5, False, **flags)
     monkeypatch.setenv('RRI_ONCHIP_SPIN_LIMIT', '0')
+    monkeypatch.setenv('RRI_ONCHIP_BACKOFF_MS', '0')       # the process-wide back-off after a fallback (2 s) would keep the later handles of this test off the path
     with onchip(True), engine(n, d, k, dtype=np.float32) as e:
         e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
         assert e.onchip_info()[0] is True
@@ -224,6 +225,7 @@ def test_a_fallback_when_a_paused_run_resumes_takes_over_at_the_same_half_step(m
             events += 1
             if events == give_up_from_event:
                 monkeypatch.setenv('RRI_ONCHIP_SPIN_LIMIT', '0')
+                monkeypatch.setenv('RRI_ONCHIP_BACKOFF_MS', '0')
             st = e._lib.rri_resume(e._h, C.byref(done))
         e._check(st)
         monkeypatch.delenv('RRI_ONCHIP_SPIN_LIMIT', raising=False)
@@ -238,6 +240,30 @@ def test_a_fallback_when_a_paused_run_resumes_takes_over_at_the_same_half_step(m
     assert fa == 1 and na == 2 and fb == 0 and nb == 0, (fa, na, fb, nb)      # two persistent launches, the second gave up
     assert ea == eb >= k and la == lb
     assert relfro(Wa, Wb) < 1e-10 and relfro(Ta, Tb) < 1e-10, (relfro(Wa, Wb), relfro(Ta, Tb))
+
+
+def test_a_fallback_backs_the_whole_process_off_the_persistent_path_for_a_while(monkeypatch):
+    """a launch that gave up means the device is shared with somebody whose grids collide with ours (four processes on one GPU:
+    5-13 collisions in 400 calls, tools/onchip_two_processes.py): a process that makes a handle per nmf() call must not walk
+    into the same wait with every new handle -- for RRI_ONCHIP_BACKOFF_MS (default 2000) no handle of the process is eligible"""
+    import time
+    n, d, k = 3000, 800, 6
+    X = planted_X(n, d, k, seed=71, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=72)
+    monkeypatch.setenv('RRI_ONCHIP_SPIN_LIMIT', '0')
+    monkeypatch.setenv('RRI_ONCHIP_BACKOFF_MS', '700')
+    with onchip(True), engine(n, d, k, dtype=np.float32) as e:
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params()
+        e.sweep(1)
+        assert e.onchip_fallbacks() == 1
+    monkeypatch.delenv('RRI_ONCHIP_SPIN_LIMIT')
+    with onchip(True), engine(n, d, k, dtype=np.float32) as e2:
+        e2.upload_X(X), e2.set_W(W0), e2.set_T(T0), e2.set_params()
+        assert e2.onchip_info()[0] is False                 # a NEW handle, inside the back-off
+        time.sleep(0.9)
+        assert e2.onchip_info()[0] is True                  # ... and after it
+        e2.sweep(1)
+        assert e2.onchip_info() == (True, 1) and e2.onchip_fallbacks() == 0
 
 
 def test_two_handles_of_different_instantiations_on_two_streams_are_ordered():

@@ -90,6 +90,46 @@ __device__ __forceinline__ S wave_sum(S v) {
     v += dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
     return lane_get(v, 63);
 }
+// Integer sum and float64 maximum over a fully active wave, wave-uniform, by the same six DPP steps (a __shfl_xor butterfly is
+// six ds_bpermute round trips through the LDS crossbar, ~0.3 us of dependent latency: too much for a reduction that sits in an
+// iteration on one wave).  For the maximum the lanes a step does not write keep their own value.
+// sum over the aligned group of 8 (4) lanes a lane belongs to, in every lane of the group: the butterfly of __shfl_xor 1, 2, 4
+// with the same additions
+__device__ __forceinline__ double group4_sum(double v) {
+    v += dpp<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += dpp<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ double group8_sum(double v) {
+    v = group4_sum(v);
+    v += dpp<0x141, 0xf>(v);     // row_half_mirror: the other quad of the 8 lanes
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += dpp_i32<0xB1, 0xf>(v);
+    v += dpp_i32<0x4E, 0xf>(v);
+    v += dpp_i32<0x141, 0xf>(v);
+    v += dpp_i32<0x140, 0xf>(v);
+    v += dpp_i32<0x142, 0xa>(v);
+    v += dpp_i32<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_keep(double v) {
+    const int l = __double2loint(v), h = __double2hiint(v);
+    const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_keep<0xB1, 0xf>(v));
+    v = fmax(v, dpp_keep<0x4E, 0xf>(v));
+    v = fmax(v, dpp_keep<0x141, 0xf>(v));
+    v = fmax(v, dpp_keep<0x140, 0xf>(v));
+    v = fmax(v, dpp_keep<0x142, 0xa>(v));
+    v = fmax(v, dpp_keep<0x143, 0xc>(v));
+    return lane_get(v, 63);
+}
 // Sums of 8 rows at once: v[u] is this lane's partial of row u (u < 8).  The wave parks the 8 x 64 partials in
 // a PRIVATE LDS tile (8 rows x 72 doubles, padded), re-reads them transposed -- lane = (row r = lane>>3,
 // part p = lane&7) adds the 8 partials p*8..p*8+7 of row r -- and three DPP steps add the 8 parts.  Returns

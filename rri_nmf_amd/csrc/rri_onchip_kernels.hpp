@@ -60,7 +60,8 @@ struct OnchipArgs {
     double* mkZ;                   // [2][G][LD]   column-sum partials of the carried topic (two buffers: by the parity of the step that reads)
     double* mkG;                   // [2][k+2][G]  Gram-row partials | ||w||^2 | column sum of the last update, entry-major
     double* mkP;                   // [k+1][64]  T T[t]^T partials | row sum of the new T row, entry-major (NA <= 64 workers)
-    double* xraw;                  // [LD]  the T row before its projection (topic-model flags): slices from the workers
+    double* mkX;                   // [2][LD]  the T row before its projection (topic-model flags): slices from the workers, by the
+                                   // parity of the step; an element that has not arrived holds ONCHIP_ABSENT
     double* xyp; int xy_stride;    // <w_t, X t_t> partials for the objective (XYpart[t * xy_stride + b])
     unsigned* bar;                 // [0] abort word, [64 + w] flagA of worker w, [64 + 64 + b] flagB of workgroup b (zero at launch)
     int G, NA, rows_wg, CG, RG, kS;
@@ -79,6 +80,12 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 __device__ __forceinline__ double ld_agent(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, RRI_AGENT));
 }
+
+// An exchange slot that has not been written in this step: a NaN payload no arithmetic produces.  The readers poll the DATA
+// (one trip to the memory side) instead of a flag and then the data (two).
+constexpr unsigned long long ONCHIP_ABSENT = 0xfff7a5a5fff7a5a5ULL;
+__device__ __forceinline__ bool onchip_absent(double v) { return (unsigned long long)__double_as_longlong(v) == ONCHIP_ABSENT; }
+__device__ __forceinline__ double onchip_absent_value() { return __longlong_as_double((long long)ONCHIP_ABSENT); }
 
 // this workgroup's data of the step is on the memory side: publish `value` in `mine`
 __device__ __forceinline__ void onchip_signal(unsigned* mine, unsigned value) {
@@ -185,15 +192,27 @@ __device__ __forceinline__ double onchip_simplex_theta(double v0, double v1, dou
     return theta;
 }
 
-// The same fixed point by ONE wave, the row left in LDS (LD <= 1024: 16 elements per lane, re-read in every iteration:
+// The same fixed point by ONE wave, the row left in LDS (LD <= 1024: 16 elements per lane, re-read in every pass:
 // 8 KB at 128 B per clock, no registers held) -- no workgroup barrier inside the iteration.  The 8-wave form above costs
 // two barriers per iteration plus two block sums around it, ~30 barriers per projected row, on the critical path of every
 // topic step of the topic-model flags; this one needs two (before and after).  The elements are w_j = row[j] when !shifted,
 // max(row[j] - shift, 0) when shifted (the second projection of nmf.py:759-761 runs on the first one's result without
-// storing it in between).  Returns theta; *sum_all = the sum over all d elements, *sum_proj = sum_j max(w_j - theta, 0).
-// Every lane returns the same values.
+// storing it in between).
+//
+// Every pass over the row costs ~0.35 us on this one wave (16 LDS reads, two dependent wave sums, a float64 division), so the
+// passes are what is counted here:
+//   * the iteration climbs to theta* from any lower bound and ends at the same active set, hence the same theta (the sum
+//     over that set in this lane order).  Two lower bounds are known before it starts: Michelot's own first iterate
+//     (sum of all - s) / d, and max(w) - s (the largest element alone already reaches s there).  From the larger of the two
+//     an ill-scaled row -- closed-form rows of the first sweeps sum to thousands where the simplex wants 1, three elements
+//     stay active -- needs 1-2 iterations instead of 9;
+//   * sum_j max(w_j - theta, 0) is accumulated lane-locally in every pass: the pass that finds the active set unchanged has
+//     computed it for the final theta (the same terms in the same order as a pass of its own);
+//   * the second projection starts from the first one's outputs: the sum of its elements IS the first one's sum_proj and
+//     their maximum is max(vmax - shift, 0) -- no opening pass (start->have).
+struct OnchipThetaStart { bool have; double all, vmax; };
 __device__ __forceinline__ double onchip_wave_theta(const double* row, int d, double s, bool shifted, double shift,
-                                                    double* sum_all, double* sum_proj, int* iters) {
+                                                    OnchipThetaStart start, double* sum_all, double* vmax_out, double* sum_proj, int* iters) {
     const int lane = threadIdx.x & 63;
     auto elem = [&](int q) -> double {
         const int j = lane + 64 * q;
@@ -201,47 +220,47 @@ __device__ __forceinline__ double onchip_wave_theta(const double* row, int d, do
         const double v = row[j];
         return shifted ? fmax(v - shift, 0.0) : v;
     };
-    // The iteration climbs to theta* from any lower bound and ends at the same active set, hence the same theta (the sum over
-    // that set in this lane order).  Two lower bounds are known before it starts: Michelot's own first iterate
-    // (sum of all - s) / d, and max(w) - s (the largest element alone already reaches s there).  From the larger of the two
-    // an ill-scaled row -- closed-form rows of the first sweeps sum to thousands where the simplex wants 1, three elements
-    // stay active -- needs 1-2 iterations instead of 9 (each costs ~0.4 us on this one wave: 16 LDS reads, two wave sums,
-    // a float64 division; profiles/r03_onchip_tm_sections.log).
-    double all = 0.0, vmax = -1.0e300;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const double v = elem(q);
-        if (v > -1.0e299) { all += v; vmax = fmax(vmax, v); }
-    }
-    all = wave_sum<double>(all);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
-    double theta = fmax((all - s) / (double)d, vmax - s);
-    i64 cnt_prev = -1;
-    int it = 1;
-    for (; it < 2 * 1024 + 2; ++it) {
-        double sum = 0.0;
-        int cnt_i = 0;
+    double all = start.all, vmax = start.vmax;
+    if (!start.have) {
+        all = 0.0; vmax = -1.0e300;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const double v = elem(q);
-            if (v > theta) { sum += v; cnt_i += 1; }
+            if (v > -1.0e299) { all += v; vmax = fmax(vmax, v); }
+        }
+        all = wave_sum<double>(all);
+        vmax = wave_max(vmax);
+    }
+    double theta = fmax((all - s) / (double)d, vmax - s);
+    i64 cnt_prev = -1;
+    int it = 1;
+    double sp = 0.0;
+    for (; it < 2 * 1024 + 2; ++it) {
+        double sum = 0.0;
+        int cnt_i = 0;
+        sp = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double v = elem(q);
+            if (v > theta) { sum += v; cnt_i += 1; sp += v - theta; }
         }
         sum = wave_sum<double>(sum);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt_i += __shfl_xor(cnt_i, off, 64);
+        cnt_i = wave_sum_i32(cnt_i);
         const i64 ci = (i64)cnt_i;
         if (ci == cnt_prev || ci == 0) break;
         theta = (sum - s) / (double)cnt_i;
         cnt_prev = ci;
     }
-    double sp = 0.0;
+    if (it >= 2 * 1024 + 2) {                  // not reached (the active set shrinks in every pass): the sum for the last theta
+        sp = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const double v = elem(q);
-        if (v > -1.0e299) sp += fmax(v - theta, 0.0);
+        for (int q = 0; q < 16; ++q) {
+            const double v = elem(q);
+            if (v > theta) sp += v - theta;
+        }
     }
     *sum_all = all;
+    *vmax_out = vmax;
     *sum_proj = wave_sum<double>(sp);
     *iters = it;
     return theta;
@@ -416,6 +435,10 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // hold a part of the CUs (tools/onchip_two_processes.py: 5-13 times in 400 calls with four processes on one GPU) -- fails
     // HERE, after entry_spin_limit polls (~tens of milliseconds) instead of the seconds of the in-run bound, with nothing to
     // undo; the host reruns the range launch by launch and backs the process off the persistent path for a while.
+    if (project && worker && tid < 2 * CWA) {              // both buffers of the row exchange start "absent" (own slice)
+        const int which = tid / CWA, jl = tid % CWA;
+        if (j0 + jl < a.LD) st_agent(a.mkX + (size_t)which * a.LD + (unsigned)(j0 + jl), onchip_absent_value());
+    }
     epoch += 1u;
     onchip_signal(flagB + b, epoch);
     if (onchip_wait(a.bar, flagB, G, epoch, a.entry_spin_limit) == 2) goto sync_failed;
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     if (code != 0) halt_bit = 0x80000000u;     // every worker takes the same verdict from the same sums
                     else if (tid < 8 * CWA) {
                         // the closed form for the own columns: 8 lanes per column share the PG partial column sums and the
-                        // k-term product with the Gram row (all their LDS reads in flight at once), three shuffles add the parts
+                        // k-term product with the Gram row (all their LDS reads in flight at once), three DPP steps add the parts
                         const int jc = tid >> 3, sub = tid & 7;
                         constexpr int TERMS = (ONCHIP_MAX_K + 7) / 8;
                         double zpart = 0.0, acc = 0.0;
@@ -495,15 +518,15 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         for (int q = 0; q < PG / 8; ++q) zpart += zq[q];
 #pragma unroll
                         for (int q = 0; q < TERMS; ++q) acc = fma(gv[q], tvv[q], acc);
-                        zpart += __shfl_xor(zpart, 1, 8); zpart += __shfl_xor(zpart, 2, 8); zpart += __shfl_xor(zpart, 4, 8);
-                        acc += __shfl_xor(acc, 1, 8); acc += __shfl_xor(acc, 2, 8); acc += __shfl_xor(acc, 4, 8);
+                        zpart = group8_sum(zpart);
+                        acc = group8_sum(acc);
                         if (sub == 0 && j0 + jc < a.d) {
                             const double numer = (zpart - acc) - p.reg_t_l1;
                             double x;
                             if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
                             else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
                             else x = numer;                        // mode 2: the arg-max of the numerator takes it all
-                            if (project) st_agent(a.xraw + (unsigned)(j0 + jc), x);
+                            if (project) st_agent(a.mkX + (size_t)buf * a.LD + (unsigned)(j0 + jc), onchip_absent(x) ? __longlong_as_double(0x7ff8000000000000LL) : x);
                             else {
                                 Tl[t * CWA + jc] = x;
                                 st_agent(a.T + (i64)t * a.ldt + j0 + jc, x);
@@ -518,14 +541,37 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         // simplex projection, or the one-hot row -- and the checks of _project_and_check_reset_t
                         // (nmf.py:751-769), exactly as k_trow_final does; all workers come to the same row and verdict
                         RRI_STAMP(8);                          // closed form of the own columns
-                        epoch += 1u;
-                        onchip_signal(flagA + b, epoch);
-                        RRI_STAMP(9);                          // slice published
-                        if (onchip_wait(a.bar, flagA, NA, epoch, a.spin_limit) == 2) goto sync_failed;
-                        RRI_STAMP(10);                         // the other workers' slices are there
-                        for (int j = tid; j < a.LD; j += NTH) rowsh[j] = j < a.d ? ld_agent(a.xraw + (unsigned)j) : 0.0;
-                        __syncthreads();
-                        RRI_STAMP(11);                         // the whole row in LDS
+                        // No flag for this exchange: the slices were stored into the step's buffer of mkX, whose slots held
+                        // ONCHIP_ABSENT, and every thread polls the two elements it stages until both are there -- store, then
+                        // ONE trip to the memory side, where a flag costs acknowledge + barrier + flag store + flag poll + the
+                        // load of the data.  The polls are bounded like those of the flags.
+                        {
+                            const double* xin = a.mkX + (size_t)buf * a.LD;
+                            const bool need0 = tid < a.d, need1 = tid + NTH < a.d;
+                            double r0 = need0 ? onchip_absent_value() : 0.0, r1 = need1 ? onchip_absent_value() : 0.0;
+                            unsigned spins = 0;
+                            int failed = 0;
+                            for (;;) {
+                                if (need0 && onchip_absent(r0)) r0 = ld_agent(xin + (unsigned)tid);
+                                if (need1 && onchip_absent(r1)) r1 = ld_agent(xin + (unsigned)(tid + NTH));
+                                if (__all(!onchip_absent(r0) && !onchip_absent(r1))) break;
+                                if ((++spins & 63u) == 0u && __hip_atomic_load(a.bar, __ATOMIC_RELAXED, RRI_AGENT) != 0u) { failed = 1; break; }
+                                if (spins > a.spin_limit) {
+                                    if (lane == 0) __hip_atomic_store(a.bar, 1u, __ATOMIC_RELAXED, RRI_AGENT);
+                                    failed = 1;
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            if (tid < a.LD) rowsh[tid] = r0;
+                            if (tid + NTH < a.LD) rowsh[tid + NTH] = r1;
+                            if (__syncthreads_or(failed)) goto sync_failed;
+                            // the other buffer is the next step's: its slots of the own slice go back to "absent".  Every worker
+                            // has stored this step's slice, so all of them are past their reads of the step before; the stores
+                            // are acknowledged before this workgroup's flagA below, which every reader of the next step waits for
+                            if (tid < CWA && j0 + tid < a.LD) st_agent(a.mkX + (size_t)(buf ^ 1) * a.LD + (unsigned)(j0 + tid), onchip_absent_value());
+                        }
+                        RRI_STAMP(10);                         // the whole row in LDS
                         double nx = 1.0, sumT = 0.0;
                         int iters = 0;
                         if (mode == 2) {
@@ -552,13 +598,15 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             // {theta1, theta2, second projection taken, sum of the row, sum after the first projection,
                             // iterations} in scratch; everybody applies them.  Two barriers instead of ~30 per row.
                             if (wave == 0) {
-                                double all = 0.0, sp = 0.0, sp2 = 0.0, all2 = 0.0;
+                                double all = 0.0, vmax = 0.0, sp = 0.0, sp2 = 0.0, all2 = 0.0, vmax2 = 0.0;
                                 int it1 = 0, it2 = 0;
-                                const double th1 = onchip_wave_theta(rowsh, a.d, p.t_row_sum, false, 0.0, &all, &sp, &it1);
+                                const double th1 = onchip_wave_theta(rowsh, a.d, p.t_row_sum, false, 0.0, OnchipThetaStart{false, 0.0, 0.0},
+                                                                     &all, &vmax, &sp, &it1);
                                 double th2 = 0.0, again = 0.0;
                                 if ((sp > 1e-10 || p.reset_method == RESET_NONE) && p.t_row_sum != 0.0 && fabs(sp - p.t_row_sum) > 1e-15) {
                                     again = 1.0;                              // nmf.py:759-761: project again
-                                    th2 = onchip_wave_theta(rowsh, a.d, p.t_row_sum, true, th1, &all2, &sp2, &it2);
+                                    th2 = onchip_wave_theta(rowsh, a.d, p.t_row_sum, true, th1, OnchipThetaStart{true, sp, fmax(vmax - th1, 0.0)},
+                                                            &all2, &vmax2, &sp2, &it2);
                                 }
                                 if (lane == 0) {
                                     scratch[0] = th1; scratch[1] = th2; scratch[2] = again; scratch[3] = all; scratch[4] = sp;
@@ -598,9 +646,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             st_agent(a.T + (i64)t * a.ldt + j0 + tid, x);
                         }
                         __syncthreads();
-                    } else if (project) {
-                        epoch += 1u;                           // the stage that is skipped still counts: every workgroup's
-                    }                                          // epoch advances alike
+                    }
                 }
                 if (halt_bit == 0u) {
                     // T T[t]^T over the own slice; [k] = sum of the row.  Thread = (entry e, quarter of the 32 columns): 8 LDS
@@ -617,7 +663,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         double acc = 0.0;
 #pragma unroll
                         for (int q = 0; q < 8; ++q) acc = fma(lv[q], xv[q], acc);
-                        const double a1 = __shfl_down(acc, 1, 4), a2 = __shfl_down(acc, 2, 4), a3 = __shfl_down(acc, 3, 4);
+                        const double a1 = dpp<0x55, 0xf>(acc), a2 = dpp<0xAA, 0xf>(acc), a3 = dpp<0xFF, 0xf>(acc);   // lanes 1, 2, 3 of the quad
                         if (part == 0 && e < k + 1) st_agent(a.mkP + (unsigned)(e * 64 + b), ((acc + a1) + a2) + a3);
                     }
                 }
@@ -625,7 +671,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 onchip_signal(flagA + b, epoch | halt_bit);
                 RRI_STAMP(1);
             } else {
-                epoch += (update_T && project) ? 2u : 1u;
+                epoch += 1u;
             }
             if (halt_bit == 0u && !last_step) carry_pre((t + 1) % k, t, buf ^ 1);   // while the flags travel
             {
@@ -691,7 +737,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 __syncthreads();
                 RRI_STAMP(4);
                 // W column t for the own rows: 8 lanes per row share the k-term dot (lane sub takes the topics sub, sub + 8,
-                // sub + 16: all their LDS reads in flight at once) and the CG row-dot partials; three shuffles add the parts
+                // sub + 16: all their LDS reads in flight at once) and the CG row-dot partials; three DPP steps add the parts
                 for (int r0 = 0; r0 < rows_here; r0 += NTH / 8) {
                     const int i = r0 + (tid >> 3), sub = tid & 7;
                     constexpr int TERMS = (ONCHIP_MAX_K + 7) / 8;
@@ -708,8 +754,8 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
 #pragma unroll
                         for (int q = 0; q < TERMS; ++q) part = fma(wv[q], sv[q], part);
                     }
-                    part += __shfl_xor(part, 1, 8); part += __shfl_xor(part, 2, 8); part += __shfl_xor(part, 4, 8);
-                    y += __shfl_xor(y, 1, 8); y += __shfl_xor(y, 2, 8);          // CG <= 4 partials, in lanes 0 .. 3
+                    part = group8_sum(part);
+                    y = group4_sum(y);                                           // CG <= 4 partials, in lanes 0 .. 3
                     if (i < rows_here && sub == 0) {
                         const double numer = (y - part) - p.reg_w_l1;
                         double wnew;

@@ -225,7 +225,7 @@ struct rri_ctx {
 
     // register-resident sweeps (rri_onchip_kernels.hpp): per-workgroup partial arrays and the grid barrier's counter
     int n_cu = 0;
-    double *mkZ = nullptr, *mkG = nullptr, *mkP = nullptr, *mkX = nullptr;
+    double *mkZ = nullptr, *mkG = nullptr, *mkP = nullptr, *mkX = nullptr, *mkT = nullptr;
     unsigned* mkbar = nullptr;
     long onchip_launches = 0;
     // a persistent launch whose workgroups could not synchronise (HALT_ERR_GRID_SYNC: the device was shared, not every
@@ -1339,7 +1339,7 @@ struct OnchipGeom { int CG, RG, rows_wg, rpw, NA, kS, G; size_t shmem; };
 constexpr int ONCHIP_MAX_RPW = 20;    // rows per wave held in registers (float4 each): 32 spills at 256 VGPRs
 bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     if (c->LD > 1024 || c->n_cu < 1) return false;
-    g->G = c->n_cu;
+    g->G = std::min(c->n_cu, 256);                     // the workers take 16 partials per lane group: G <= 16 ONCHIP_PG
     g->CG = c->LD <= 256 ? 1 : c->LD <= 512 ? 2 : 4;
     g->RG = ONCHIP_WAVES / g->CG;
     g->rows_wg = (int)((c->n + g->G - 1) / g->G);
@@ -1417,21 +1417,22 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     if (!c->mkZ) {
         if (hipMalloc((void**)&c->mkZ, (size_t)2 * g.G * c->LD * 8) != hipSuccess) { c->mkZ = nullptr; return false; }
         if (hipMalloc((void**)&c->mkG, (size_t)2 * g.G * (k + 2) * 8) != hipSuccess) return false;
-        if (hipMalloc((void**)&c->mkP, (size_t)64 * (k + 1) * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->mkP, (size_t)2 * 64 * (k + 1) * 8) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkbar, (size_t)(128 + g.G) * sizeof(unsigned)) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkX, (size_t)2 * c->LD * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->mkT, (size_t)2 * c->LD * 8) != hipSuccess) return false;
         (void)hipMemsetAsync(c->mkZ, 0, (size_t)2 * g.G * c->LD * 8, c->stream);
         (void)hipMemsetAsync(c->mkG, 0, (size_t)2 * g.G * (k + 2) * 8, c->stream);
-        (void)hipMemsetAsync(c->mkP, 0, (size_t)64 * (k + 1) * 8, c->stream);
+        (void)hipMemsetAsync(c->mkP, 0, (size_t)2 * 64 * (k + 1) * 8, c->stream);
     }
-    if (!c->mkG || !c->mkP || !c->mkbar || !c->mkX) return false;
+    if (!c->mkG || !c->mkP || !c->mkbar || !c->mkX || !c->mkT) return false;
     if (!c->Wsafe && hipMalloc((void**)&c->Wsafe, (size_t)k * c->ldw * 8) != hipSuccess) { c->Wsafe = nullptr; return false; }
     if (!c->Tsafe && hipMalloc((void**)&c->Tsafe, (size_t)k * c->LD * 8) != hipSuccess) { c->Tsafe = nullptr; return false; }
     (void)hipMemsetAsync(c->mkbar, 0, (size_t)(128 + g.G) * sizeof(unsigned), c->stream);
     OnchipArgs a{};
     a.X = c->X; a.ldx = c->ldx; a.n = (int)c->n; a.d = (int)c->d; a.LD = (int)c->LD; a.k = k;
     a.Wt = c->W; a.ldw = c->ldw; a.T = c->T; a.ldt = c->LD;
-    a.mkZ = c->mkZ; a.mkG = c->mkG; a.mkP = c->mkP; a.mkX = c->mkX; a.xyp = c->XYpart; a.xy_stride = c->xy_stride; a.bar = c->mkbar;
+    a.mkZ = c->mkZ; a.mkG = c->mkG; a.mkP = c->mkP; a.mkX = c->mkX; a.mkT = c->mkT; a.xyp = c->XYpart; a.xy_stride = c->xy_stride; a.bar = c->mkbar;
     a.G = g.G; a.NA = g.NA; a.rows_wg = g.rows_wg; a.CG = g.CG; a.RG = g.RG; a.kS = g.kS;
     a.s0 = cur.sweep; a.t0 = cur.topic; a.ph0 = cur.phase; a.s_end = c->run_total;
     a.skip_row_finish = c->skip_row_finish ? 1 : 0;
@@ -1807,7 +1808,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)

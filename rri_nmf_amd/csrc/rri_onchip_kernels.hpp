@@ -57,13 +57,16 @@ constexpr int ONCHIP_PG = ONCHIP_THREADS / ONCHIP_CWA;   // groups of workgroup 
 struct OnchipArgs {
     const void* X; i64 ldx; int n, d, LD, k;      // X in the handle's storage type (the kernel is instantiated per type)
     double* Wt; i64 ldw; double* T; i64 ldt;
-    double* mkZ;                   // [2][G][LD]   column-sum partials of the carried topic (two buffers: by the parity of the step that reads)
+    // exchange arrays: two buffers each, by the parity of the step that reads; a slot holds ONCHIP_ABSENT until its value of the
+    // step is stored
+    double* mkZ;                   // [2][G][LD]   column-sum partials of the carried topic
     double* mkG;                   // [2][k+2][G]  Gram-row partials | ||w||^2 | column sum of the last update, entry-major
-    double* mkP;                   // [k+1][64]  T T[t]^T partials | row sum of the new T row, entry-major (NA <= 64 workers)
+    double* mkP;                   // [2][k+1][64]  T T[t]^T partials | row sum of the new T row, entry-major (NA <= 64 workers)
+    double* mkT;                   // [2][LD]  the T row of the step, slices from the workers
     double* mkX;                   // [2][LD]  the T row before its projection (topic-model flags): slices from the workers, by the
                                    // parity of the step; an element that has not arrived holds ONCHIP_ABSENT
     double* xyp; int xy_stride;    // <w_t, X t_t> partials for the objective (XYpart[t * xy_stride + b])
-    unsigned* bar;                 // [0] abort word, [64 + w] flagA of worker w, [64 + 64 + b] flagB of workgroup b (zero at launch)
+    unsigned* bar;                 // [0] abort word, [128 + b] the entry flag of workgroup b (zero at launch)
     int G, NA, rows_wg, CG, RG, kS;
     int s0, t0, ph0, s_end;        // cursor (sweep, topic, phase) and end sweep (exclusive)
     int skip_row_finish;           // a resumed W half whose T-row checks already ran (after a T-row reset)
@@ -81,11 +84,86 @@ __device__ __forceinline__ double ld_agent(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, RRI_AGENT));
 }
 
-// An exchange slot that has not been written in this step: a NaN payload no arithmetic produces.  The readers poll the DATA
-// (one trip to the memory side) instead of a flag and then the data (two).
-constexpr unsigned long long ONCHIP_ABSENT = 0xfff7a5a5fff7a5a5ULL;
-__device__ __forceinline__ bool onchip_absent(double v) { return (unsigned long long)__double_as_longlong(v) == ONCHIP_ABSENT; }
-__device__ __forceinline__ double onchip_absent_value() { return __longlong_as_double((long long)ONCHIP_ABSENT); }
+// What crosses workgroups inside the sweep carries its own "it is there": every exchange slot holds ONCHIP_ABSENT until the value
+// of the step is stored into it, and the readers poll the DATA until none of what they loaded is absent -- store, then ONE trip
+// to the memory side, where a flag costs acknowledge + barrier + flag store + flag poll + the load of the data behind it
+// (profiles/r03_onchip_tm_sections.log: 3.75 -> 1.9 us for the exchange of the row slices).  The markers are NaNs with a
+// payload no arithmetic produces; they are told by their high word, and a store of real data that happened to carry one of
+// them (an input NaN of that very pattern) is rewritten to the canonical NaN.  ONCHIP_HALTED in a slot: the workers ended the
+// step with an event or an error (DevState says which) and every reader returns.
+constexpr unsigned ONCHIP_ABSENT_HI = 0xfff7a5a5u, ONCHIP_HALTED_HI = 0xfff7a5a6u;
+__device__ __forceinline__ bool onchip_absent(double v) { return (unsigned)__double2hiint(v) == ONCHIP_ABSENT_HI; }
+__device__ __forceinline__ bool onchip_halted(double v) { return (unsigned)__double2hiint(v) == ONCHIP_HALTED_HI; }
+__device__ __forceinline__ double onchip_absent_value() { return __hiloint2double((int)ONCHIP_ABSENT_HI, (int)ONCHIP_ABSENT_HI); }
+__device__ __forceinline__ double onchip_halted_value() { return __hiloint2double((int)ONCHIP_HALTED_HI, (int)ONCHIP_HALTED_HI); }
+__device__ __forceinline__ void st_data(double* p, double v) {
+    const unsigned hi = (unsigned)__double2hiint(v);
+    st_agent(p, (hi == ONCHIP_ABSENT_HI || hi == ONCHIP_HALTED_HI) ? __longlong_as_double(0x7ff8000000000000LL) : v);
+}
+// this wave's agent-scope stores so far have been acknowledged (what a later store -- after a workgroup barrier: of any wave
+// -- may rely on having landed first)
+__device__ __forceinline__ void onchip_stores_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Loads v[u] = base[off(u)] (0.0 where off(u) is ONCHIP_NONE) until none is absent: `base` is wave-uniform, the offsets are
+// recomputed for every round of loads rather than kept (registers), and a round that found something absent is repeated as a
+// whole after a short sleep.  Every lane of the wave calls; returns, wave-uniform, 0 = all there, 2 = the grid gave up (the
+// abort word, or this wave ran out of polls and raised it).
+// (issue / finish apart: the first rounds of two polls can be in flight together)
+constexpr unsigned ONCHIP_NONE = 0xffffffffu;
+// The steps of a sweep are alike: what a wave waited for in the step before it will wait for again, about as long.  2048 waves
+// that poll a few kilobytes for the 10 us a projected T row takes keep the memory side busy with exactly the channels the
+// workers' own exchange goes through (topic-model flags at 10000 x 1000: 22.9 -> 32.3 us per topic step), so a wave sleeps
+// through the first part of a wait it has reason to expect before its first load.  The estimate only moves on evidence, and
+// never close to the expected arrival -- a wave that oversleeps delays the workgroups that wait for IT, whose waits then look
+// longer, and with naps that track the whole wait that feeds on itself (measured: 500 us per topic step):
+//   a wait that needed more than one round of loads saw the data arrive: nap 5/8 of that wait next time;
+//   a wait whose first round found everything there may have overslept: nap 3/4 of the last nap.
+// (ticks of 100 MHz)
+struct OnchipNap {
+    int ticks = 0;
+    long long t0 = 0;
+    __device__ __forceinline__ void before() {
+        t0 = wall_clock64();
+        const long long until = t0 + ticks;
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(4);
+    }
+    __device__ __forceinline__ void after(int rounds) {
+        ticks = rounds > 0 ? ((int)(wall_clock64() - t0) * 5) >> 3 : (ticks * 3) >> 2;
+    }
+};
+// (off(u, z): z is a zero the compiler cannot see through, to be added to the lane-dependent term of the offset -- otherwise the
+// offsets of the repeated round are loop-invariant, get hoisted out of the polling loop and are kept in registers after all)
+template <int N, typename OffFn>
+__device__ __forceinline__ void onchip_poll_issue(const double* base, OffFn off, double (&v)[N]) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const unsigned o = off(u, z);
+        v[u] = o != ONCHIP_NONE ? ld_agent(base + o) : 0.0;
+    }
+}
+template <int N, typename OffFn>
+__device__ __forceinline__ int onchip_poll_finish(const double* base, OffFn off, double (&v)[N], unsigned* bar, unsigned spin_limit,
+                                                  int* rounds = nullptr) {
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < N; ++u) ok = ok && !onchip_absent(v[u]);
+        if (__all(ok)) {
+            if (rounds) *rounds = (int)spins;
+            return 0;
+        }
+        if ((++spins & 15u) == 0u && __hip_atomic_load(bar, __ATOMIC_RELAXED, RRI_AGENT) != 0u) return 2;
+        if (spins > spin_limit) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(bar, 1u, __ATOMIC_RELAXED, RRI_AGENT);
+            return 2;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        onchip_poll_issue<N>(base, off, v);
+    }
+}
 
 // this workgroup's data of the step is on the memory side: publish `value` in `mine`
 __device__ __forceinline__ void onchip_signal(unsigned* mine, unsigned value) {
@@ -125,42 +203,38 @@ __device__ __forceinline__ int onchip_wait(unsigned* bar, const unsigned* flags,
     return v;
 }
 
-// sums over `np` workgroup partials part[q * stride + e] for the entries e = wave, wave + 8, ... < ne, into out[e]: the
+// sums over `np` <= 256 workgroup partials part[e * stride + q] for the entries e = wave, wave + 8, ... < ne, into out[e]: the
 // loads of up to 3 entries (4 partials per lane each) are in flight together -- one round trip for k <= 22 -- and every
-// workgroup adds in the same order
+// workgroup adds in the same order.  The partials are exchange slots: polled until they are there (onchip_poll).  Returns 0,
+// or 2 = the grid gave up; *halted is raised when a partial carries the workers' halt marker.
 // (entry-major arrays: the np partials of an entry are contiguous, `stride` doubles per entry -- with workgroup-major rows every
 // 8-byte load of a partial touched a sector of its own, eight times the bytes)
-__device__ __forceinline__ void onchip_entry_sums(const double* __restrict__ part, int stride, int ne, int np, double* out,
-                                                  int wave, int lane) {
+__device__ __forceinline__ int onchip_entry_sums(const double* part, int stride, int ne, int np, double* out, int wave, int lane,
+                                                 unsigned* bar, unsigned spin_limit, int* halted) {
     constexpr int EB = 3;
+    int failed = 0;
     for (int e0 = wave; e0 < ne; e0 += ONCHIP_WAVES * EB) {
-        double acc[EB];
-#pragma unroll
-        for (int m = 0; m < EB; ++m) acc[m] = 0.0;
-#pragma unroll 1
-        for (int q0 = lane; q0 < np; q0 += 256) {
-            double v[EB][4];
-#pragma unroll
-            for (int m = 0; m < EB; ++m) {
-                const int e = e0 + ONCHIP_WAVES * m;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = q0 + 64 * u;
-                    v[m][u] = (e < ne && q < np) ? ld_agent(part + (unsigned)(e * stride + q)) : 0.0;
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < EB; ++m)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[m] += v[m][u];
-        }
+        double v[EB * 4];
+        auto off = [&](int i, int z) -> unsigned {
+            const int e = e0 + ONCHIP_WAVES * (i >> 2), q = lane + z + 64 * (i & 3);
+            return (e < ne && q < np) ? (unsigned)(e * stride + q) : ONCHIP_NONE;
+        };
+        onchip_poll_issue<EB * 4>(part, off, v);
+        failed |= onchip_poll_finish<EB * 4>(part, off, v, bar, spin_limit);
 #pragma unroll
         for (int m = 0; m < EB; ++m) {
             const int e = e0 + ONCHIP_WAVES * m;
-            const double tot = wave_sum<double>(acc[m]);
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc += v[m * 4 + u];
+                if (onchip_halted(v[m * 4 + u])) *halted = 1;
+            }
+            const double tot = wave_sum<double>(acc);
             if (lane == 0 && e < ne) out[e] = tot;
         }
     }
+    return failed;
 }
 
 // Michelot's fixed point for the simplex projection of a row held two elements per thread (v0 = row[tid], v1 = row[tid + 512];
@@ -214,11 +288,11 @@ struct OnchipThetaStart { bool have; double all, vmax; };
 __device__ __forceinline__ double onchip_wave_theta(const double* row, int d, double s, bool shifted, double shift,
                                                     OnchipThetaStart start, double* sum_all, double* vmax_out, double* sum_proj, int* iters) {
     const int lane = threadIdx.x & 63;
+    // row[d .. 1024) holds -1e300 ("no element"): no bound checks here -- sixteen lane masks kept across the passes were
+    // sixteen scratch reloads inside every pass
     auto elem = [&](int q) -> double {
-        const int j = lane + 64 * q;
-        if (j >= d) return -1.0e300;
-        const double v = row[j];
-        return shifted ? fmax(v - shift, 0.0) : v;
+        const double v = row[lane + 64 * q];
+        return shifted ? (v < -1.0e299 ? v : fmax(v - shift, 0.0)) : v;
     };
     double all = start.all, vmax = start.vmax;
     if (!start.have) {
@@ -285,17 +359,16 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
             dlast = now_;                                                      \
         }                                                                      \
     } while (0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // taken anew in every topic step: see zstep below
     const int b = blockIdx.x, G = a.G, NA = a.NA, k = a.k, kS = a.kS, CG = a.CG, RG = a.RG;
-    const int cg = wave % CG, rg = wave / CG;
-    const int col0 = cg * 256 + lane * 4;
+    int cg = wave % CG, rg = wave / CG;
+    int col0 = cg * 256 + lane * 4;
     const int row0 = b * a.rows_wg;
     const int rows_here = max(0, min(a.rows_wg, a.n - row0));
     const bool worker = b < NA;
     const int j0 = b * CWA;                                 // first column of a worker's T slice
     const KParams p = a.p;
-    unsigned* flagA = a.bar + 64;
-    unsigned* flagB = a.bar + 128;
+    unsigned* flagB = a.bar + 128;                          // the entry hand-over
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* Wl = reinterpret_cast<double*>(smem);           // [rows_wg][kS]   own rows of W
@@ -354,8 +427,6 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
         }
     __syncthreads();
 
-    unsigned epoch = 0;       // number of the last hand-over; advances identically in every workgroup
-
     // The carry of topic tn -- column sums w_tn^T X and Gram-row partials of w_tn over the own rows -- in two parts.
     // carry_pre: everything that does not depend on the W column `texcl` of the running step (column tn itself is not
     // touched by that step): the column sums, ||w_tn||^2 and the Gram entries against every other column.  It runs while
@@ -363,6 +434,13 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // 10000 x 1000; running it two steps ahead, in the workers' own wait, measured the same).  carry_post: the two
     // entries that need the updated column t.  The arrays are double-buffered by the parity of the step that READS them,
     // so the workers may still be reading the running step's buffer while the next one is written.
+    // zstep: a zero the compiler cannot see through, taken anew in every topic step and added to the thread index, from which
+    // lane, wave, row group and column are then derived again.  Without it every per-thread LDS offset, global offset and lane
+    // mask of the step (the unrolled loops over 20 rows alone: 20 registers + 20 mask pairs each) is invariant across steps,
+    // gets hoisted out of the sweep loop, does not fit next to the resident X and comes back from scratch one by one inside the
+    // loops it was hoisted from: a scratch load and a wait per row on the critical path (100-130 spilled registers in the
+    // topic-model instantiation; none in the plain one, 60 with the projection).
+    int zstep = 0;
     auto carry_pre = [&](int tn, int texcl, int buf) {
         double* mkZb = a.mkZ + (size_t)buf * G * a.LD;
         double* mkGb = a.mkG + (size_t)buf * (k + 2) * G;
@@ -390,7 +468,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (q < RG) s += zq[q];
-            st_agent(mkZb + (unsigned)(b * a.LD + j), s);
+            st_data(mkZb + (unsigned)(b * a.LD + j), s);
         }
 #pragma unroll 1
         for (int e = wave; e < k + 1; e += NWV) {
@@ -402,7 +480,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 acc = fma(wn, e < k ? Wl[(size_t)i * kS + e] : wn, acc);
             }
             acc = wave_sum<double>(acc);
-            if (lane == 0) st_agent(mkGb + (unsigned)(e * G + b), acc);
+            if (lane == 0) st_data(mkGb + (unsigned)(e * G + b), acc);
         }
         __syncthreads();                                           // zsh is free again
     };
@@ -416,17 +494,11 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 acc = wave == 0 ? fma(Wl[(size_t)i * kS + tn], wt, acc) : acc + wt;
             }
             acc = wave_sum<double>(acc);
-            if (lane == 0) st_agent(mkGb + (unsigned)((wave == 0 ? t : k + 1) * G + b), acc);
+            if (lane == 0) st_data(mkGb + (unsigned)((wave == 0 ? t : k + 1) * G + b), acc);
         }
     };
-    // phase B of every workgroup is done -> flagB; the workers wait for all of them
-    auto hand_to_workers = [&]() -> int {
-        epoch += 1u;
-        onchip_signal(flagB + b, epoch);
-        return worker ? onchip_wait(a.bar, flagB, G, epoch, a.spin_limit) : 0;
-    };
-
     bool have_carry = false;
+    OnchipNap napA, napB;          // this wave's waits for the carries (workers) / for the workers
     int chk = 0, tprev = -1;
     unsigned stepq = 0;       // topic steps of this launch so far
 
@@ -435,47 +507,73 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // hold a part of the CUs (tools/onchip_two_processes.py: 5-13 times in 400 calls with four processes on one GPU) -- fails
     // HERE, after entry_spin_limit polls (~tens of milliseconds) instead of the seconds of the in-run bound, with nothing to
     // undo; the host reruns the range launch by launch and backs the process off the persistent path for a while.
-    if (project && worker && tid < 2 * CWA) {              // both buffers of the row exchange start "absent" (own slice)
-        const int which = tid / CWA, jl = tid % CWA;
-        if (j0 + jl < a.LD) st_agent(a.mkX + (size_t)which * a.LD + (unsigned)(j0 + jl), onchip_absent_value());
+    // Every exchange slot this workgroup owns starts "absent", in both buffers.
+    for (int e = tid; e < 2 * a.LD; e += NTH) st_agent(a.mkZ + (size_t)(e / a.LD) * G * a.LD + (unsigned)(b * a.LD + e % a.LD), onchip_absent_value());
+    if (tid < 2 * (k + 2)) st_agent(a.mkG + (size_t)(tid / (k + 2)) * (k + 2) * G + (unsigned)((tid % (k + 2)) * G + b), onchip_absent_value());
+    if (worker) {
+        if (tid < 2 * CWA) {
+            const int which = tid / CWA, jl = tid % CWA;
+            if (j0 + jl < a.LD) {
+                st_agent(a.mkT + (size_t)which * a.LD + (unsigned)(j0 + jl), onchip_absent_value());
+                st_agent(a.mkX + (size_t)which * a.LD + (unsigned)(j0 + jl), onchip_absent_value());
+            }
+        }
+        if (tid >= 64 && tid < 64 + 2 * (k + 1)) {
+            const int e = tid - 64;
+            st_agent(a.mkP + (size_t)(e / (k + 1)) * (k + 1) * 64 + (unsigned)((e % (k + 1)) * 64 + b), onchip_absent_value());
+        }
     }
-    epoch += 1u;
-    onchip_signal(flagB + b, epoch);
-    if (onchip_wait(a.bar, flagB, G, epoch, a.entry_spin_limit) == 2) goto sync_failed;
+    onchip_signal(flagB + b, 1u);
+    if (onchip_wait(a.bar, flagB, G, 1u, a.entry_spin_limit) == 2) goto sync_failed;
     for (int s = a.s0; s < a.s_end; ++s) {
         for (int t = (s == a.s0) ? a.t0 : 0; t < k; ++t) {
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zstep));
+            tid = (int)threadIdx.x + zstep; lane = tid & 63; wave = tid >> 6;
+            cg = wave % CG; rg = wave / CG; col0 = cg * 256 + lane * 4;
+            tile = tiles + wave * (8 * 72);
             const int ph = (s == a.s0 && t == a.t0) ? a.ph0 : 0;
             const bool update_T = ph == 0;
             int mode = 0;
             const int buf = (int)(stepq & 1u);             // buffers phase A of this step reads; the next step's are buf ^ 1
             const bool last_step = (s == a.s_end - 1) && (t == k - 1);
-            if (update_T && !have_carry) {
-                carry_pre(t, -1, buf);
-                if (hand_to_workers() == 2) goto sync_failed;
-            }
+            const double* mkZr = a.mkZ + (size_t)buf * G * a.LD;
+            const double* mkGr = a.mkG + (size_t)buf * (k + 2) * G;
+            double* mkPw = a.mkP + (size_t)buf * (k + 1) * 64;
+            double* mkTw = a.mkT + (size_t)buf * a.LD;
+            if (update_T && !have_carry) carry_pre(t, -1, buf);      // the first step of a launch: no check pending (chk == 0), the
+                                                                     // column-sum entry k + 1 is neither written nor read
             // ---------------- phase A (workers): T row t on the own column slice -----------------------------------
             RRI_STAMP(7);
             unsigned halt_bit = 0u;
             if (worker) {
                 if (update_T) {
-                    // the partials of the own columns: thread = (column jl, group pg of workgroups pg, pg + PG, ...)
+                    // the partials of the own columns: thread = (column jl, group pg of workgroups pg, pg + PG, ...); G <= 16 PG.
+                    // Polled until every workgroup's carry of the step is there -- this is the hand-over from phase B
                     const int jl = tid % CWA, pg = tid / CWA;
-                    const double* mkZr = a.mkZ + (size_t)buf * G * a.LD;
                     double zp[16];
                     const bool col_ok = j0 + jl < a.LD;
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int q = pg + PG * u;
-                        zp[u] = (col_ok && q < G) ? ld_agent(mkZr + (unsigned)(q * a.LD + j0 + jl)) : 0.0;
-                    }
-                    onchip_entry_sums(a.mkG + (size_t)buf * (k + 2) * G, G, k + 2, G, gsh, wave, lane);
+                    auto zoff = [&](int u, int z) -> unsigned {
+                        const int q = pg + z + PG * u;
+                        return (col_ok && q < G) ? (unsigned)(q * a.LD + j0 + jl) : ONCHIP_NONE;
+                    };
+                    napA.before();
+                    onchip_poll_issue<16>(mkZr, zoff, zp);
+                    int never = 0;
+                    int failed = onchip_entry_sums(mkGr, G, k + 1 + chk, G, gsh, wave, lane, a.bar, a.spin_limit, &never);
+                    int roundsA = 0;
+                    failed |= onchip_poll_finish<16>(mkZr, zoff, zp, a.bar, a.spin_limit, &roundsA);
+                    napA.after(roundsA);
                     double zacc = 0.0;
 #pragma unroll
                     for (int u = 0; u < 16; ++u) zacc += zp[u];
-#pragma unroll 1
-                    for (int q = pg + PG * 16; q < G; q += PG) zacc += col_ok ? ld_agent(mkZr + (unsigned)(q * a.LD + j0 + jl)) : 0.0;
                     zred[pg * CWA + jl] = zacc;
-                    __syncthreads();
+                    if (__syncthreads_or(failed)) goto sync_failed;
+                    // Every workgroup's carry of this step is here, so all of them are past their reads of the step before: this
+                    // worker's slots of the OTHER buffers of mkT / mkP (the next step's) go back to "absent".  The stores are
+                    // acknowledged (onchip_stores_landed, then a barrier) before anything of this step is stored for the
+                    // others, so whoever has seen this step's values cannot find last-but-one step's in those slots.
+                    if (tid < CWA && j0 + tid < a.LD) st_agent(a.mkT + (size_t)(buf ^ 1) * a.LD + (unsigned)(j0 + tid), onchip_absent_value());
+                    if (tid >= 64 && tid < 64 + k + 1) st_agent(a.mkP + (size_t)(buf ^ 1) * (k + 1) * 64 + (unsigned)((tid - 64) * 64 + b), onchip_absent_value());
                     RRI_STAMP(0);
                     const double nw = gsh[k];
                     int code = 0;
@@ -526,13 +624,14 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             if (mode == 0) x = fmax(numer, 0.0) / (c + p.eps);
                             else if (mode == 1) x = (-numer + c < 0.0) ? p.t_row_sum : 0.0;
                             else x = numer;                        // mode 2: the arg-max of the numerator takes it all
-                            if (project) st_agent(a.mkX + (size_t)buf * a.LD + (unsigned)(j0 + jc), onchip_absent(x) ? __longlong_as_double(0x7ff8000000000000LL) : x);
+                            if (project) st_data(a.mkX + (size_t)buf * a.LD + (unsigned)(j0 + jc), x);
                             else {
                                 Tl[t * CWA + jc] = x;
                                 st_agent(a.T + (i64)t * a.ldt + j0 + jc, x);
                             }
                         }
                     }
+                    onchip_stores_landed();
                     __syncthreads();
                     if (b == 0 && tid == 0 && code == 0) st->tmode = mode;
                     if (project && code == 0) {
@@ -541,34 +640,20 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         // simplex projection, or the one-hot row -- and the checks of _project_and_check_reset_t
                         // (nmf.py:751-769), exactly as k_trow_final does; all workers come to the same row and verdict
                         RRI_STAMP(8);                          // closed form of the own columns
-                        // No flag for this exchange: the slices were stored into the step's buffer of mkX, whose slots held
-                        // ONCHIP_ABSENT, and every thread polls the two elements it stages until both are there -- store, then
-                        // ONE trip to the memory side, where a flag costs acknowledge + barrier + flag store + flag poll + the
-                        // load of the data.  The polls are bounded like those of the flags.
+                        // the slices are exchange slots of the step's buffer of mkX: every thread polls the two elements it stages
                         {
                             const double* xin = a.mkX + (size_t)buf * a.LD;
-                            const bool need0 = tid < a.d, need1 = tid + NTH < a.d;
-                            double r0 = need0 ? onchip_absent_value() : 0.0, r1 = need1 ? onchip_absent_value() : 0.0;
-                            unsigned spins = 0;
-                            int failed = 0;
-                            for (;;) {
-                                if (need0 && onchip_absent(r0)) r0 = ld_agent(xin + (unsigned)tid);
-                                if (need1 && onchip_absent(r1)) r1 = ld_agent(xin + (unsigned)(tid + NTH));
-                                if (__all(!onchip_absent(r0) && !onchip_absent(r1))) break;
-                                if ((++spins & 63u) == 0u && __hip_atomic_load(a.bar, __ATOMIC_RELAXED, RRI_AGENT) != 0u) { failed = 1; break; }
-                                if (spins > a.spin_limit) {
-                                    if (lane == 0) __hip_atomic_store(a.bar, 1u, __ATOMIC_RELAXED, RRI_AGENT);
-                                    failed = 1;
-                                    break;
-                                }
-                                __builtin_amdgcn_s_sleep(1);
-                            }
-                            if (tid < a.LD) rowsh[tid] = r0;
-                            if (tid + NTH < a.LD) rowsh[tid + NTH] = r1;
+                            double r[2];
+                            auto xoff = [&](int u, int z) -> unsigned { return tid + z + NTH * u < a.d ? (unsigned)(tid + z + NTH * u) : ONCHIP_NONE; };
+                            onchip_poll_issue<2>(xin, xoff, r);
+                            const int failed = onchip_poll_finish<2>(xin, xoff, r, a.bar, a.spin_limit);
+                            rowsh[tid] = tid < a.d ? r[0] : -1.0e300;                    // past d: "no element" for the fixed point
+                            rowsh[tid + NTH] = tid + NTH < a.d ? r[1] : -1.0e300;
                             if (__syncthreads_or(failed)) goto sync_failed;
                             // the other buffer is the next step's: its slots of the own slice go back to "absent".  Every worker
                             // has stored this step's slice, so all of them are past their reads of the step before; the stores
-                            // are acknowledged before this workgroup's flagA below, which every reader of the next step waits for
+                            // are acknowledged before this workgroup's carry of the next step (phase B), which every reader of the
+                            // next step's slices has polled first
                             if (tid < CWA && j0 + tid < a.LD) st_agent(a.mkX + (size_t)(buf ^ 1) * a.LD + (unsigned)(j0 + tid), onchip_absent_value());
                         }
                         RRI_STAMP(10);                         // the whole row in LDS
@@ -649,8 +734,10 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     }
                 }
                 if (halt_bit == 0u) {
-                    // T T[t]^T over the own slice; [k] = sum of the row.  Thread = (entry e, quarter of the 32 columns): 8 LDS
-                    // reads in flight each, the four quarters of an entry sit in adjacent lanes and are added in order
+                    // the row of the step for everybody (columns past d: zeros), then T T[t]^T over the own slice; [k] = sum of
+                    // the row.  Thread = (entry e, quarter of the 32 columns): 8 LDS reads in flight each, the four quarters of
+                    // an entry sit in adjacent lanes and are added in order
+                    if (tid < CWA && j0 + tid < a.LD) st_data(mkTw + (unsigned)(j0 + tid), Tl[t * CWA + tid]);
                     for (int e0 = 0; e0 < k + 1; e0 += NTH / 4) {
                         const int e = e0 + (tid >> 2), part = tid & 3;
                         double xv[8], lv[8];
@@ -664,32 +751,44 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
 #pragma unroll
                         for (int q = 0; q < 8; ++q) acc = fma(lv[q], xv[q], acc);
                         const double a1 = dpp<0x55, 0xf>(acc), a2 = dpp<0xAA, 0xf>(acc), a3 = dpp<0xFF, 0xf>(acc);   // lanes 1, 2, 3 of the quad
-                        if (part == 0 && e < k + 1) st_agent(a.mkP + (unsigned)(e * 64 + b), ((acc + a1) + a2) + a3);
+                        if (part == 0 && e < k + 1) st_data(mkPw + (unsigned)(e * 64 + b), ((acc + a1) + a2) + a3);
                     }
+                } else {
+                    // an event or an error (DevState says which; every worker has come to the same verdict from the same sums):
+                    // the halt marker in every slot the others poll
+                    if (tid < CWA && j0 + tid < a.LD) st_agent(mkTw + (unsigned)(j0 + tid), onchip_halted_value());
+                    if (tid >= 64 && tid < 64 + k + 1) st_agent(mkPw + (unsigned)((tid - 64) * 64 + b), onchip_halted_value());
                 }
-                epoch += 1u;
-                onchip_signal(flagA + b, epoch | halt_bit);
                 RRI_STAMP(1);
-            } else {
-                epoch += 1u;
             }
-            if (halt_bit == 0u && !last_step) carry_pre((t + 1) % k, t, buf ^ 1);   // while the flags travel
-            {
-                const int v = onchip_wait(a.bar, flagA, NA, epoch, a.spin_limit);
-                if (v == 2) goto sync_failed;
-                if (v == 1) return;                        // the workers found an event or an error: DevState says which
-            }
-            RRI_STAMP(2);
-            // mode of the T row for the diagnostics below: only workgroup 0 (a worker) reports it
+            if (halt_bit == 0u && !last_step) carry_pre((t + 1) % k, t, buf ^ 1);   // while the workers' stores travel
 
             // ---------------- phase B: row checks, W column t on the own rows, carry of topic t + 1 ---------------
             {
-                double tv[4] = {0.0, 0.0, 0.0, 0.0};
+                // the hand-over from the workers: the T row (this lane's 4 columns) and the partials of T T[t]^T, polled until
+                // every worker's are there
+                double tv[4];
+                auto toff = [&](int c, int z) -> unsigned { return col0 + z + c < a.LD ? (unsigned)(col0 + z + c) : ONCHIP_NONE; };
+                napB.before();
+                onchip_poll_issue<4>(mkTw, toff, tv);
+                int halted = 0;
+                int failed = onchip_entry_sums(mkPw, 64, k + 1, NA, tts, wave, lane, a.bar, a.spin_limit, &halted);
+                int roundsB = 0;
+                failed |= onchip_poll_finish<4>(mkTw, toff, tv, a.bar, a.spin_limit, &roundsB);
+                napB.after(roundsB);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (col0 + c < a.LD) tv[c] = ld_agent(a.T + (unsigned)(t * (int)a.ldt + col0 + c));
-                onchip_entry_sums(a.mkP, 64, k + 1, NA, tts, wave, lane);
-                __syncthreads();
+                    if (onchip_halted(tv[c])) halted = 1;
+                if (__syncthreads_or(failed | halted)) {
+                    if (__syncthreads_or(failed)) goto sync_failed;
+                    return;                                // the workers found an event or an error: DevState says which
+                }
+                RRI_STAMP(2);
+                // every worker has stored its row of the step, so all of them are past their reads of this step's carry: the own
+                // slots of THIS step's buffers of mkZ / mkG (read again two steps on) go back to "absent", acknowledged before
+                // the last entries of the next step's carry are stored (carry_post, after the barrier below)
+                for (int j = tid; j < a.LD; j += NTH) st_agent(a.mkZ + (size_t)buf * G * a.LD + (unsigned)(b * a.LD + j), onchip_absent_value());
+                if (tid < k + 2) st_agent(a.mkG + (size_t)buf * (k + 2) * G + (unsigned)(tid * G + b), onchip_absent_value());
                 RRI_STAMP(3);
                 const bool row_checks = !project && (update_T || !a.skip_row_finish);     // with a projection: done in phase A
                 if (row_checks) {                          // _project_and_check_reset_t without a projection (nmf.py:751-769)
@@ -766,6 +865,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         xyl[i] = wnew * y;
                     }
                 }
+                onchip_stores_landed();                    // the "absent" marks above (and a worker's of phase A) before carry_post
                 __syncthreads();
                 if (wave == 0) {                           // <w_t, X t_t> over the own rows: the objective's cross term
                     double acc = 0.0;
@@ -781,22 +881,22 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 tprev = t;
                 have_carry = true;
             }
-            if (hand_to_workers() == 2) goto sync_failed;
             stepq += 1u;
         }
     }
     RRI_STAMP(7);
     if (DBG && a.dbg && tid == 0 && (b == 0 || b == G - 1))
         for (int i = 0; i < 14; ++i) a.dbg[(b == 0 ? 0 : 16) + i] = dacc[i];
-    // the column check of the last W update of the call (position of the next step: sweep s_end, topic 0): workgroup 0 is
-    // a worker and has waited for every workgroup's partials
+    // the column check of the last W update of the call (position of the next step: sweep s_end, topic 0): workgroup 0
+    // polls every workgroup's partial of the column sum (G <= 256: four per lane)
     if (chk && b == 0) {
-        const double v = [&]() {
-            double acc = 0.0;
-#pragma unroll 1
-            for (int q = lane; q < G; q += 64) acc += ld_agent(a.mkG + (size_t)(stepq & 1u) * (k + 2) * G + (unsigned)((k + 1) * G + q));
-            return wave_sum<double>(acc);
-        }();
+        double cs[4];
+        const double* last = a.mkG + (size_t)(stepq & 1u) * (k + 2) * G + (unsigned)((k + 1) * G);
+        auto coff = [&](int u, int z) -> unsigned { return lane + z + 64 * u < G ? (unsigned)(lane + z + 64 * u) : ONCHIP_NONE; };
+        onchip_poll_issue<4>(last, coff, cs);
+        const int failed = onchip_poll_finish<4>(last, coff, cs, a.bar, a.spin_limit);
+        if (__syncthreads_or(failed)) goto sync_failed;
+        const double v = wave_sum<double>(((cs[0] + cs[1]) + cs[2]) + cs[3]);
         if (tid == 0) {
             const bool ev = (v <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
             const bool err = !ev && !(v > 0.0);

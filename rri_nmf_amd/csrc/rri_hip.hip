@@ -1338,9 +1338,10 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
 struct OnchipGeom { int CG, RG, rows_wg, rpw, NA, kS, G; size_t shmem; };
 constexpr int ONCHIP_MAX_RPW = 20;    // rows per wave held in registers (float4 each): 32 spills at 256 VGPRs
 bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
-    if (c->LD > 1024 || c->n_cu < 1) return false;
+    const bool proj = !LK::light(c);                   // the projection stage stages the whole T row per worker: d <= 1024
+    if (c->LD > (proj ? 1024 : 2048) || c->n_cu < 1) return false;
     g->G = std::min(c->n_cu, 256);                     // the workers take 16 partials per lane group: G <= 16 ONCHIP_PG
-    g->CG = c->LD <= 256 ? 1 : c->LD <= 512 ? 2 : 4;
+    g->CG = c->LD <= 256 ? 1 : c->LD <= 512 ? 2 : c->LD <= 1024 ? 4 : 8;
     g->RG = ONCHIP_WAVES / g->CG;
     g->rows_wg = (int)((c->n + g->G - 1) / g->G);
     g->rpw = (g->rows_wg + g->RG - 1) / g->RG;
@@ -1392,18 +1393,18 @@ hipError_t onchip_ordered_launch(rri_ctx* c, const void* fn, int grid, size_t sh
     if (le == hipSuccess && g_onchip_last[dv]) (void)hipEventRecord(g_onchip_last[dv], c->stream);
     return le;
 }
-template <typename SX, int RPW, bool DBG = false, bool PROJ = false>
+template <typename SX, int RPW, bool DBG = false, bool PROJ = false, int KT = 3>
 hipError_t onchip_launch(rri_ctx* c, const OnchipGeom& g, const OnchipArgs& a) {
     static bool attr_set[64] = {};
     const int dv = c->device & 63;
-    const void* fn = (const void*)k_onchip_sweeps<SX, RPW, DBG, PROJ>;
+    const void* fn = (const void*)k_onchip_sweeps<SX, RPW, DBG, PROJ, KT>;
     if (!attr_set[dv]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: hipFuncSetAttribute\n"); return e; }
         attr_set[dv] = true;
     }
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onchip_sweeps<SX, RPW, DBG, PROJ>, ONCHIP_THREADS, g.shmem);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onchip_sweeps<SX, RPW, DBG, PROJ, KT>, ONCHIP_THREADS, g.shmem);
     if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: occupancy %d per CU (%s), %d CUs\n", per_cu, hipGetErrorString(e), c->n_cu);
     if (e != hipSuccess) return e;
     if ((i64)per_cu * c->n_cu < g.G) return hipErrorCooperativeLaunchTooLarge;     // the hand-overs need every workgroup resident
@@ -1440,6 +1441,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     a.entry_spin_limit = 40000u;        // the hand-over at kernel entry: a grid that is not resident as a whole shows within ~40 ms
     if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = a.entry_spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
     if (const char* e = getenv("RRI_ONCHIP_ENTRY_SPIN_LIMIT")) a.entry_spin_limit = (unsigned)std::max(0, atoi(e));
+    a.nap_eighths = 5;
+    if (const char* e = getenv("RRI_ONCHIP_NAP_EIGHTHS")) a.nap_eighths = std::min(7, std::max(0, atoi(e)));      // diagnostics
     a.p = kparams(c); a.st = c->st;
     a.dbg = nullptr;
     if (getenv("RRI_ONCHIP_TIMING")) {           // diagnostics: per-section ticks of the last launch, printed at the next one
@@ -1470,7 +1473,13 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         const bool timed = c->timing > 0 && c->timed[0].size() < 400000;
         if (timed) { tl.a = get_event(c); tl.b = get_event(c); (void)hipEventRecord(tl.a, c->stream); }
         const bool proj = !LK::light(c);          // project_T_each_iter with a t_row_sum: the topic-model instantiation
-        if (c->dtype == RRI_F64) {                // 8 registers per row and lane: half the rows of the fp32 instantiations
+        if (c->k > ONCHIP_SMALL_K) {              // k-term dots of 8 terms per lane (k <= 64); no diagnostics build
+            if (c->dtype == RRI_F64) {
+                if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true, 8>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, true, 8>(c, g, a);
+                else e = g.rpw <= 4 ? onchip_launch<double, 4, false, false, 8>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, false, 8>(c, g, a);
+            } else if (proj) e = g.rpw <= 8 ? onchip_launch<float, 8, false, true, 8>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, true, 8>(c, g, a);
+            else e = g.rpw <= 8 ? onchip_launch<float, 8, false, false, 8>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, false, 8>(c, g, a);
+        } else if (c->dtype == RRI_F64) {         // 8 registers per row and lane: half the rows of the fp32 instantiations
             if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, true>(c, g, a);
             else e = g.rpw <= 4 ? onchip_launch<double, 4>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2>(c, g, a);
         } else if (proj && a.dbg) e = g.rpw <= 8 ? onchip_launch<float, 8, true, true>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, true, true>(c, g, a);

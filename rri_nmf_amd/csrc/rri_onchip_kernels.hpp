@@ -48,9 +48,8 @@ namespace rri {
 
 enum { HALT_ERR_GRID_SYNC = -8 };
 constexpr int ONCHIP_THREADS = 512, ONCHIP_WAVES = ONCHIP_THREADS / 64;
-constexpr int ONCHIP_MAX_K = 22;      // k + 2 Gram entries = 8 waves x 3 in flight: one round trip in phase A.  Beyond that the
-                                      // per-topic cost of the kernel grows faster than that of the launch-per-phase schedule
-                                      // (5000 x 1000: -3 % at k = 24 and 32, -15 % at k = 64; profiles/r02_onchip_sizes.log)
+constexpr int ONCHIP_SMALL_K = 22;    // k + 2 Gram entries = 8 waves x 3 in flight: one round of loads in phase A (KT = 3)
+constexpr int ONCHIP_MAX_K = 64;      // KT = 8: two rounds beyond k = 46
 constexpr int ONCHIP_CWA = 32;          // columns of T per worker
 constexpr int ONCHIP_PG = ONCHIP_THREADS / ONCHIP_CWA;   // groups of workgroup partials in the column-sum reduction
 
@@ -71,6 +70,7 @@ struct OnchipArgs {
     int s0, t0, ph0, s_end;        // cursor (sweep, topic, phase) and end sweep (exclusive)
     int skip_row_finish;           // a resumed W half whose T-row checks already ran (after a T-row reset)
     unsigned spin_limit;
+    int nap_eighths;               // share of an observed wait slept through before the first load of the next one, in eighths
     unsigned entry_spin_limit;     // polls of the all-grid hand-over at kernel entry (short: a grid that is not resident as a whole shows here)
     long long* dbg;                // diagnostics build only: [2][16] accumulated 100 MHz ticks per section (workgroup 0, workgroup G-1)
     KParams p; DevState* st;
@@ -127,8 +127,8 @@ struct OnchipNap {
         const long long until = t0 + ticks;
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(4);
     }
-    __device__ __forceinline__ void after(int rounds) {
-        ticks = rounds > 0 ? ((int)(wall_clock64() - t0) * 5) >> 3 : (ticks * 3) >> 2;
+    __device__ __forceinline__ void after(int rounds, int eighths) {      // eighths: 5 (RRI_ONCHIP_NAP_EIGHTHS; 0 = no naps)
+        ticks = rounds > 0 ? ((int)(wall_clock64() - t0) * eighths) >> 3 : (ticks * 3) >> 2;
     }
 };
 // (off(u, z): z is a zero the compiler cannot see through, to be added to the lane-dependent term of the offset -- otherwise the
@@ -203,32 +203,34 @@ __device__ __forceinline__ int onchip_wait(unsigned* bar, const unsigned* flags,
     return v;
 }
 
-// sums over `np` <= 256 workgroup partials part[e * stride + q] for the entries e = wave, wave + 8, ... < ne, into out[e]: the
-// loads of up to 3 entries (4 partials per lane each) are in flight together -- one round trip for k <= 22 -- and every
-// workgroup adds in the same order.  The partials are exchange slots: polled until they are there (onchip_poll).  Returns 0,
+// sums over `np` <= 64 PPL workgroup partials part[e * stride + q] for the entries e = wave, wave + 8, ... < ne, into out[e]: a
+// lane takes PPL partials of an entry (4 for the G <= 256 partials of the carries, 1 for the NA <= 64 of the workers) and NL
+// loads are in flight together, i.e. 8 NL / PPL entries per round of loads -- one round for k <= 22 at NL = 12 -- and every
+// workgroup adds in the same order.  The partials are exchange slots: polled until they are there (onchip_poll_*).  Returns 0,
 // or 2 = the grid gave up; *halted is raised when a partial carries the workers' halt marker.
 // (entry-major arrays: the np partials of an entry are contiguous, `stride` doubles per entry -- with workgroup-major rows every
 // 8-byte load of a partial touched a sector of its own, eight times the bytes)
+template <int NL, int PPL>
 __device__ __forceinline__ int onchip_entry_sums(const double* part, int stride, int ne, int np, double* out, int wave, int lane,
                                                  unsigned* bar, unsigned spin_limit, int* halted) {
-    constexpr int EB = 3;
+    constexpr int EB = NL / PPL;
     int failed = 0;
     for (int e0 = wave; e0 < ne; e0 += ONCHIP_WAVES * EB) {
-        double v[EB * 4];
+        double v[NL];
         auto off = [&](int i, int z) -> unsigned {
-            const int e = e0 + ONCHIP_WAVES * (i >> 2), q = lane + z + 64 * (i & 3);
+            const int e = e0 + ONCHIP_WAVES * (i / PPL), q = lane + z + 64 * (i % PPL);
             return (e < ne && q < np) ? (unsigned)(e * stride + q) : ONCHIP_NONE;
         };
-        onchip_poll_issue<EB * 4>(part, off, v);
-        failed |= onchip_poll_finish<EB * 4>(part, off, v, bar, spin_limit);
+        onchip_poll_issue<NL>(part, off, v);
+        failed |= onchip_poll_finish<NL>(part, off, v, bar, spin_limit);
 #pragma unroll
         for (int m = 0; m < EB; ++m) {
             const int e = e0 + ONCHIP_WAVES * m;
             double acc = 0.0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc += v[m * 4 + u];
-                if (onchip_halted(v[m * 4 + u])) *halted = 1;
+            for (int u = 0; u < PPL; ++u) {
+                acc += v[m * PPL + u];
+                if (onchip_halted(v[m * PPL + u])) *halted = 1;
             }
             const double tot = wave_sum<double>(acc);
             if (lane == 0 && e < ne) out[e] = tot;
@@ -344,7 +346,8 @@ __device__ __forceinline__ double onchip_wave_theta(const double* row, int d, do
 // tools/onchip_probe.py): 0 phase A loads, 1 phase A rest + signal, 2 wait for the workers, 3 phase B loads, 4 row dots,
 // 5 W update, 6 carry, 7 hand-over to the workers
 // PROJ: the instantiation for the topic-model flags (the projection stage costs the plain one registers it does not have)
-template <typename SX, int RPW, bool DBG = false, bool PROJ = false>
+// KT: k-term dots take KT terms per lane of an 8-lane group: 3 for k <= 24, 8 for k <= 64 (same sums: the terms past k are zeros)
+template <typename SX, int RPW, bool DBG = false, bool PROJ = false, int KT = 3>
 __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) {
     constexpr int NTH = ONCHIP_THREADS, NWV = ONCHIP_WAVES, CWA = ONCHIP_CWA, PG = ONCHIP_PG;
     DevState* st = a.st;
@@ -559,10 +562,10 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     napA.before();
                     onchip_poll_issue<16>(mkZr, zoff, zp);
                     int never = 0;
-                    int failed = onchip_entry_sums(mkGr, G, k + 1 + chk, G, gsh, wave, lane, a.bar, a.spin_limit, &never);
+                    int failed = onchip_entry_sums<KT == 3 ? 12 : 24, 4>(mkGr, G, k + 1 + chk, G, gsh, wave, lane, a.bar, a.spin_limit, &never);
                     int roundsA = 0;
                     failed |= onchip_poll_finish<16>(mkZr, zoff, zp, a.bar, a.spin_limit, &roundsA);
-                    napA.after(roundsA);
+                    napA.after(roundsA, a.nap_eighths);
                     double zacc = 0.0;
 #pragma unroll
                     for (int u = 0; u < 16; ++u) zacc += zp[u];
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         // the closed form for the own columns: 8 lanes per column share the PG partial column sums and the
                         // k-term product with the Gram row (all their LDS reads in flight at once), three DPP steps add the parts
                         const int jc = tid >> 3, sub = tid & 7;
-                        constexpr int TERMS = (ONCHIP_MAX_K + 7) / 8;
+                        constexpr int TERMS = KT;
                         double zpart = 0.0, acc = 0.0;
                         double gv[TERMS], tvv[TERMS], zq[PG / 8];
 #pragma unroll
@@ -772,10 +775,10 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 napB.before();
                 onchip_poll_issue<4>(mkTw, toff, tv);
                 int halted = 0;
-                int failed = onchip_entry_sums(mkPw, 64, k + 1, NA, tts, wave, lane, a.bar, a.spin_limit, &halted);
+                int failed = onchip_entry_sums<KT == 3 ? 3 : 9, 1>(mkPw, 64, k + 1, NA, tts, wave, lane, a.bar, a.spin_limit, &halted);
                 int roundsB = 0;
                 failed |= onchip_poll_finish<4>(mkTw, toff, tv, a.bar, a.spin_limit, &roundsB);
-                napB.after(roundsB);
+                napB.after(roundsB, a.nap_eighths);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (onchip_halted(tv[c])) halted = 1;
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 // sub + 16: all their LDS reads in flight at once) and the CG row-dot partials; three DPP steps add the parts
                 for (int r0 = 0; r0 < rows_here; r0 += NTH / 8) {
                     const int i = r0 + (tid >> 3), sub = tid & 7;
-                    constexpr int TERMS = (ONCHIP_MAX_K + 7) / 8;
+                    constexpr int TERMS = KT;
                     double part = 0.0, y = 0.0;
                     if (i < rows_here) {
                         double wv[TERMS], sv[TERMS];
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         for (int q = 0; q < TERMS; ++q) part = fma(wv[q], sv[q], part);
                     }
                     part = group8_sum(part);
-                    y = group4_sum(y);                                           // CG <= 4 partials, in lanes 0 .. 3
+                    y = group8_sum(y);                                           // CG <= 8 partials, in lanes 0 .. CG - 1
                     if (i < rows_here && sub == 0) {
                         const double numer = (y - part) - p.reg_w_l1;
                         double wnew;

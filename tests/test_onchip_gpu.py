@@ -64,7 +64,9 @@ def run(X, W0, T0, sweeps, on, objective=False, dtype=np.float32, **params):
 
 
 SHAPES = [(50, 30, 3), (700, 200, 2), (1501, 333, 6), (2600, 512, 7), (4096, 1024, 5), (5003, 1000, 22), (10000, 1000, 20),
-          (300, 700, 4), (10240, 1024, 8)]
+          (300, 700, 4), (10240, 1024, 8),
+          (3001, 1000, 23), (5000, 800, 47), (5000, 1000, 64), (900, 256, 33),        # k-term dots of 8 terms per lane (k <= 64)
+          (5000, 2000, 12), (2500, 1500, 40), (5120, 2048, 3), (1000, 1030, 20)]      # 8 column groups (1024 < d <= 2048)
 
 
 @pytest.mark.parametrize('shape', SHAPES)
@@ -72,11 +74,19 @@ def test_onchip_equals_launch_per_phase(shape):
     n, d, k = shape
     X = planted_X(n, d, min(k, 20), seed=n + d, dtype=np.float32)
     W0, T0 = scaled_init(X, k, seed=5)
+    if k > 22:
+        # From a random start the first sweeps of a LONG Gauss-Seidel chain are chaotic: every topic step multiplies a rounding
+        # difference by ~1.5, and at k = 47 / 64 either schedule is 2e-5 / 2e-3 away from the CPU oracle after ONE sweep -- and
+        # 4e-6 / 3e-4 from the other (tools/onchip_large_k_check.py, profiles/r03_onchip_large_k.log).  Two sweeps on, the same
+        # comparison holds 1e-14: the kernels are compared from there.
+        W0, T0, _, _ = run(X, W0, T0, 2, False)
     Wa, Ta, oa, _ = run(X, W0, T0, 3, True, objective=True)
     Wb, Tb, ob, _ = run(X, W0, T0, 3, False, objective=True)
     # the two paths add the same terms in another order: what that leaves after 3 sweeps grows with k (the Gauss-Seidel
     # chain of a sweep from a random start amplifies a rounding difference topic by topic; 2e-11 at k = 20)
-    assert relfro(Wa, Wb) < 1e-9 and relfro(Ta, Tb) < 1e-9, (relfro(Wa, Wb), relfro(Ta, Tb))
+    print('on-chip vs launch-per-phase %s: W %.2e, T %.2e' % (shape, relfro(Wa, Wb), relfro(Ta, Tb)))
+    tol = 1e-9
+    assert relfro(Wa, Wb) < tol and relfro(Ta, Tb) < tol, (relfro(Wa, Wb), relfro(Ta, Tb))
     # after an on-chip sweep the objective comes from the cross terms the kernel left (no pass over X), as after k_wcol
     assert np.allclose(oa, ob, rtol=1e-10), (oa, ob)
     assert np.all(np.diff(oa) <= 1e-9 * oa[0])
@@ -153,10 +163,16 @@ def test_what_is_not_covered_stays_on_the_launch_per_phase_path():
             assert e.onchip_info() == (False, 0)
             e.sweep(1)
             assert e.onchip_info() == (False, 0)
-    with onchip(True), engine(n, d, 23, dtype=np.float32) as e:            # more Gram entries than one round of loads takes
+    with onchip(True), engine(n, d, 65, dtype=np.float32) as e:            # more topics than the k-term dots of the kernel take
         e.set_params()
         e.upload_X(X)
         assert e.onchip_info()[0] is False
+    Xw = np.zeros((600, 1100), dtype=np.float32)                           # the projection stage stages whole T rows: d <= 1024
+    for params, eligible in ((dict(), True), (dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0), False)):
+        with onchip(True), engine(600, 1100, 4, dtype=np.float32) as e:
+            e.set_params(**params)
+            e.upload_X(Xw)
+            assert e.onchip_info()[0] is eligible
     with onchip(True), engine(40000, 1024, 4, dtype=np.float32) as e:      # too many rows per CU for the registers
         e.set_params()
         e.upload_X(np.zeros((40000, 1024), dtype=np.float32))
@@ -316,7 +332,7 @@ def test_two_handles_of_different_instantiations_on_two_streams_are_ordered():
 TM = dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)
 
 
-@pytest.mark.parametrize('shape', [(50, 30, 3), (1501, 333, 6), (2600, 512, 7), (10000, 1000, 20), (4096, 1024, 5)])
+@pytest.mark.parametrize('shape', [(50, 30, 3), (1501, 333, 6), (2600, 512, 7), (10000, 1000, 20), (4096, 1024, 5), (3000, 700, 40)])
 def test_topic_model_flags(shape):
     """qf_min with s = t_row_sum (optimization.py:53-59) and _project_and_check_reset_t (nmf.py:751-769) inside the persistent
     kernel: both schedules, the oracle, rows of T on the simplex"""
@@ -386,7 +402,7 @@ def test_topic_model_estimator_on_the_text_fixture_in_fp32_storage():
     assert np.array_equal(np.argmax(Wa, 1), g['argmax_s10'])        # the reference's own assignments after 10 sweeps (float64 run)
 
 
-@pytest.mark.parametrize('shape', [(50, 30, 3), (1501, 333, 6), (2501, 1000, 12), (5000, 1022, 20), (2600, 510, 7)])
+@pytest.mark.parametrize('shape', [(50, 30, 3), (1501, 333, 6), (2501, 1000, 12), (5000, 1022, 20), (2600, 510, 7), (2000, 900, 36)])
 @pytest.mark.parametrize('flags', [dict(), TM])
 def test_float64_storage(shape, flags):
     """8 registers per row and lane; LD is a multiple of 2 only (the second pair of a lane's four columns may lie past the row)"""

@@ -39,6 +39,6 @@ for s in range(1, sweeps + 1):
     Wb, Tb, ib = run(False, s)
     Wc, Tc = W0.astype(np.float64).copy(), T0.astype(np.float64).copy()
     orc.plain_sweeps(X64, Wc, Tc, s)
-    print('%d sweeps, k = %d, planted rank %d: on-chip %s vs launch-per-phase W %.2e T %.2e | on-chip vs oracle W %.2e T %.2e | '
-          'launch-per-phase vs oracle W %.2e T %.2e' % (s, k, rank, ia, relfro(Wa, Wb), relfro(Ta, Tb), relfro(Wa, Wc), relfro(Ta, Tc),
+    print('%s start, %d sweeps, k = %d, planted rank %d: on-chip %s vs launch-per-phase W %.2e T %.2e | on-chip vs oracle W %.2e T %.2e | '
+          'launch-per-phase vs oracle W %.2e T %.2e' % ('warm' if 'warm' in sys.argv else 'random', s, k, rank, ia, relfro(Wa, Wb), relfro(Ta, Tb), relfro(Wa, Wc), relfro(Ta, Tc),
                                                       relfro(Wb, Wc), relfro(Tb, Tc)), flush=True)

@@ -20,26 +20,31 @@ def child(calls, sweeps):
     n, d, k = 10000, 1000, 20
     X = planted_X(n, d, k, seed=1, dtype=np.float32)
     W0, T0 = scaled_init(X, k, seed=2)
-    fallbacks, handles, worst = 0, 0, 0.0
+    fallbacks, handles, worst, onchip_calls = 0, 0, 0.0, 0
     t_all = time.perf_counter()
     eng = None
+    W, T = W0, T0
     for c in range(calls):
-        if eng is None or not eng.onchip_info()[0]:         # a handle that fell back stays on the other schedule: take a new one
-            if eng is not None:
+        if c % 20 == 0:                                     # a new handle every 20 calls, as a process that calls nmf() again and
+            if eng is not None:                             # again does; the run goes on from where the last handle stood
                 fallbacks += eng.onchip_fallbacks()
+                W, T = eng.get_W(), eng.get_T()
                 eng.close()
             eng = RRIEngine(n, d, k, dtype=np.float32)
-            eng.upload_X(X), eng.set_W(W0), eng.set_T(T0), eng.set_params()
+            eng.upload_X(X), eng.set_W(W), eng.set_T(T), eng.set_params()
             handles += 1
+        before = eng.onchip_info()[1]
         t0 = time.perf_counter()
         eng.sweep(sweeps)
         worst = max(worst, time.perf_counter() - t0)
+        onchip_calls += eng.onchip_info()[1] > before
     fallbacks += eng.onchip_fallbacks()
     wall = time.perf_counter() - t_all
     obj = eng.objective()
     eng.close()
-    print('pid %d: %d calls of %d sweeps in %.2f s (%.1f sweeps/s), handles %d, fallbacks %d, longest call %.3f s, objective %.9e'
-          % (os.getpid(), calls, sweeps, wall, calls * sweeps / wall, handles, fallbacks, worst, obj), flush=True)
+    print('pid %d: %d calls of %d sweeps in %.2f s (%.1f sweeps/s), handles %d, calls on the persistent path %d, fallbacks %d, '
+          'longest call %.3f s, objective %.12e' % (os.getpid(), calls, sweeps, wall, calls * sweeps / wall, handles, onchip_calls, fallbacks, worst, obj),
+          flush=True)
 
 
 if __name__ == '__main__':

@@ -453,7 +453,7 @@ def main():
                                 else 'k_pass<float,Y,Z,UPD=2> (rank-one residual update R <- R - a b^T - a2 b2^T, read + write, fused '
                                      'with the row dots and column sums of the new R)' if resid_sched
                                 else 'k_onchip_sweeps: ONE persistent launch for the whole call, X resident in registers (one 512-thread '
-                                     'workgroup per CU), two hand-overs between workgroups per topic step; `achieved` is algorithmic bytes '
+                                     'workgroup per CU), two exchanges between workgroups per topic step in which the data is its own hand-over; `achieved` is algorithmic bytes '
                                      '(n*d*4 per topic step) over time and no HBM figure: X is read from HBM once per call' if onchip
                                 else 'k_pass<float,Y,Z> (fused row-dot + column-sum pass over X)'),
                      'bytes_per_launch': bytes_per_launch, 'launches': launches, 'avg_ms': pass_avg_ms},

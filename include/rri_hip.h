@@ -279,15 +279,15 @@ rri_status rri_objective_parts(rri_ctx* ctx, double out[3]);
 rri_status rri_timing_enable(rri_ctx* ctx, int32_t on);
 rri_status rri_timing_read(rri_ctx* ctx, int32_t kernel_id, int64_t* launches, double* total_ms);
 rri_status rri_synchronize(rri_ctx* ctx);
-/* Launch-bound sizes: when X fits the registers of the chip -- up to about 10000 x 1024 in fp32, half the rows in float64 -- and the configuration
- * is the unweighted one with both halves free (plain, or the topic-model flags with T rows projected at every step), k in
- * 2..22, one device, rri_sweep / rri_resume run as ONE persistent launch with X resident on chip and two (topic model:
- * three) hand-overs between workgroups per topic step (rri_onchip_kernels.hpp) instead of three or four launches per topic
- * step; the whole launch is then timed as kernel_id 0.  *eligible: would the next
+/* Launch-bound sizes: when X fits the registers of the chip -- 40 MB: about 10000 x 1024 or 5000 x 2048 in fp32, half the rows in
+ * float64 -- and the configuration is the unweighted one with both halves free (plain with d <= 2048, or the topic-model flags
+ * with T rows projected at every step and d <= 1024), k in 2..64, one device, rri_sweep / rri_resume run as ONE persistent
+ * launch with X resident on chip and two (topic model: three) exchanges between workgroups per topic step
+ * (rri_onchip_kernels.hpp) instead of three or four launches per topic step; the whole launch is then timed as kernel_id 0.  *eligible: would the next
  * rri_sweep take that path; *launches: how many it has taken on this handle.  RRI_ONCHIP=0 (environment, read by
  * rri_create) switches it off.  Either pointer may be NULL. */
 rri_status rri_onchip_info(rri_ctx* ctx, int32_t* eligible, int64_t* launches);
-/* The hand-overs of that launch poll a bounded number of times.  When its workgroups cannot all run at once (a device shared
+/* The exchanges of that launch poll a bounded number of times.  When its workgroups cannot all run at once (a device shared
  * with another process, CUs masked away) the launch gives up, and the call does what the reference's sweep does under any
  * scheduling (nmf.py:415-476): it completes -- W and T are put back to what they were before the launch and the same steps
  * run on the launch-per-phase schedule, which the handle then keeps.  *fallbacks: how often that happened on this handle. */

@@ -1451,7 +1451,7 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         if (dbg) {
             long long h[32];
             if (c->onchip_launches > 0 && hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char* names[14] = {"A loads", "A rest+signal", "wait workers", "B loads", "row dots", "W update", "carry", "hand-over",
+                static const char* names[14] = {"carries arrive", "A rest", "next carry + workers arrive", "mark absent", "row dots", "W update", "carry_post", "to next step",
                                                 "closed form", "-", "slices arrive", "-", "project", "-"};
                 for (int w = 0; w < 2; ++w) {
                     fprintf(stderr, "rri on-chip sections, workgroup %s (us total):", w == 0 ? "0 (worker)" : "G-1");

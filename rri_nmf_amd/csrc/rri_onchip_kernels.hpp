@@ -4,19 +4,17 @@
 // CU.  At that size the launch-per-phase schedule (k_trow_small, k_pass, k_wcol: three dependent launches per topic
 // step, 22-24 us) spends its time on launch latencies and on re-reading a cache-resident X, not on work.  Here ONE
 // persistent kernel -- one 512-thread workgroup per CU (two waves per SIMD, 256 registers each), all co-resident --
-// loads its rows of X into registers once and runs whole sweeps; what crosses workgroups goes through small arrays on
-// the memory side and two flag hand-overs per topic step:
+// loads its rows of X into registers once and runs whole sweeps; what crosses workgroups goes through small exchange arrays
+// on the memory side, twice per topic step:
 //
 //   every workgroup b   rows [b rows_wg, (b+1) rows_wg) of X and W   (X: registers, W: LDS; the global k-major W kept current)
 //   worker w < NA       also columns [w CWA, (w+1) CWA) of T         (all k rows of that slice in LDS); NA = ceil(LD / CWA)
 //
-//   phase B (t)  all    T T[t]^T = sum_w mkP[w], row checks (nmf.py:751-769), T[t,:] into registers, y = X t for the own
-//                       rows, W-column update (nmf.py:464-469, 728-734); then for tn = t+1:
+//   phase B (t)  all    T T[t]^T = sum_w mkP[w], row checks (nmf.py:751-769), T[t,:] (mkT) into registers, y = X t for the
+//                       own rows, W-column update (nmf.py:464-469, 728-734); then for tn = t+1:
 //                       mkZ[b] = w_tn^T X, mkG[b] = (w_tn^T W, ||w_tn||^2, column sum of the update) over the own rows
-//                       -> flagB[b]; the workers wait for all G of them, the others go on to wait for the workers
 //   phase A (tn) workers  g = sum_b mkG[b], column check (nmf.py:471-476), z_j = sum_b mkZ[b][j], numer_T, qf_min for the
-//                       own columns (nmf.py:437-447, 670-676) -> T[tn, slice], mkP[w] = partial T T[tn]^T and row sum
-//                       -> flagA[w] (top bit: the step halts); everybody waits for the NA of them
+//                       own columns (nmf.py:437-447, 670-676) -> T[tn, slice] (mkT), mkP[w] = partial T T[tn]^T and row sum
 //
 // Only NA workgroups read the G x (k+2) Gram partials and everybody reads NA x (k+1) Gram partials of T: with every
 // workgroup reducing everything itself the partial sums alone moved 23 MB per topic step through the memory side, more
@@ -30,17 +28,20 @@
 //
 // Same arithmetic as the launch-per-phase kernels (same branches of qf_min, same checks, same halt protocol:
 // DevState.halt with the position of the detecting step), another order of the row / column partial sums.
-// Both halves free, 2 <= k <= 22.  With the topic-model flags (T rows projected onto the simplex at every step) the workers
-// exchange their slices of the closed-form row and each finishes the projection of the whole row: one more hand-over among
-// the 32 workers per step.
+// Both halves free, 2 <= k <= 64, d <= 2048.  With the topic-model flags (T rows projected onto the simplex at every step;
+// d <= 1024) the workers exchange their slices of the closed-form row (mkX) and each finishes the projection of the whole row:
+// one more exchange among the workers per step.
 //
-// Hand-overs (tools/barrier_probe.hip, profiles/r02_grid_barrier_variants.log): a workgroup stores the number of the
-// step in its flag; one wave of each waiting workgroup polls the flags it depends on.  Everything that crosses workgroups
-// -- the flags, mkZ / mkG / mkP and the T row of the step -- is written and read with agent-scope accesses (they go to the
-// memory side, past the per-XCD L2s), so no L2 write-back / invalidate is needed: 4.1 us per grid-wide barrier against
-// 7.9 us for a counter with release / acquire fences and 22 us when every wave issues the acquire.  The number of polls
-// is BOUNDED: a grid that cannot make progress (workgroups not co-resident) raises an abort word that every poll also
-// reads, so every wave reaches the end of the kernel and the host sees HALT_ERR_GRID_SYNC instead of a hang.
+// The exchanges (tools/barrier_probe.hip, profiles/r02_grid_barrier_variants.log, r03_onchip_sections.log): everything that
+// crosses workgroups is written and read with agent-scope accesses (they go to the memory side, past the per-XCD L2s), so no
+// L2 write-back / invalidate is needed.  Round 2 published a step with a flag per workgroup -- wait for the stores'
+// acknowledgement, barrier, flag store; the consumer polls the flags, then loads the data: two dependent trips per hand-over,
+// 2.7 us.  Now the DATA is its own hand-over: every exchange slot holds an "absent" marker until its value of the step is
+// stored, consumers poll the values themselves (one trip), and the owner of a slot marks it absent again at a point where
+// every reader is known to be past it (comments at the stores).  The only flags left are those of the all-grid hand-over at
+// kernel entry.  The number of polls is BOUNDED: a grid that cannot make progress (workgroups not co-resident) raises an abort
+// word that every poll also reads, so every wave reaches the end of the kernel and the host sees HALT_ERR_GRID_SYNC instead
+// of a hang.
 #pragma once
 #include "rri_kernels.hpp"
 
@@ -239,39 +240,11 @@ __device__ __forceinline__ int onchip_entry_sums(const double* part, int stride,
     return failed;
 }
 
-// Michelot's fixed point for the simplex projection of a row held two elements per thread (v0 = row[tid], v1 = row[tid + 512];
-// -inf where there is none): the same iteration as simplex_theta (rri_kernels.hpp), with the sum and the count of the active
-// set reduced together -- two barriers per iteration instead of eight; every thread returns the same theta
-__device__ __forceinline__ double onchip_simplex_theta(double v0, double v1, double s, double* sh, int* iters) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double theta = -1.0e300;
-    i64 cnt_prev = -1;
-    int it = 0;
-    for (; it < 2 * ONCHIP_THREADS + 2; ++it) {
-        double sum = 0.0, cnt = 0.0;
-        if (v0 > theta) { sum += v0; cnt += 1.0; }
-        if (v1 > theta) { sum += v1; cnt += 1.0; }
-        sum = wave_sum<double>(sum);
-        cnt = wave_sum<double>(cnt);
-        __syncthreads();                       // sh may still be read from the iteration before
-        if (lane == 0) { sh[wave] = sum; sh[8 + wave] = cnt; }
-        __syncthreads();
-        double S = 0.0, C = 0.0;
-#pragma unroll
-        for (int q = 0; q < ONCHIP_WAVES; ++q) { S += sh[q]; C += sh[8 + q]; }
-        const i64 ci = (i64)C;
-        if (ci == cnt_prev || ci == 0) break;
-        theta = (S - s) / C;
-        cnt_prev = ci;
-    }
-    *iters = it;
-    return theta;
-}
-
-// The same fixed point by ONE wave, the row left in LDS (LD <= 1024: 16 elements per lane, re-read in every pass:
-// 8 KB at 128 B per clock, no registers held) -- no workgroup barrier inside the iteration.  The 8-wave form above costs
-// two barriers per iteration plus two block sums around it, ~30 barriers per projected row, on the critical path of every
-// topic step of the topic-model flags; this one needs two (before and after).  The elements are w_j = row[j] when !shifted,
+// Michelot's fixed point for the simplex projection (the iteration of simplex_theta, rri_kernels.hpp) by ONE wave, the row left
+// in LDS (LD <= 1024: 16 elements per lane, re-read in every pass: 8 KB at 128 B per clock, no registers held) -- no workgroup
+// barrier inside the iteration.  Round 2's 8-wave form (two elements per thread) cost two barriers per iteration plus two block
+// sums around it, ~30 barriers per projected row, on the critical path of every topic step of the topic-model flags; this one
+// needs two (before and after).  The elements are w_j = row[j] when !shifted,
 // max(row[j] - shift, 0) when shifted (the second projection of nmf.py:759-761 runs on the first one's result without
 // storing it in between).
 //
@@ -343,8 +316,9 @@ __device__ __forceinline__ double onchip_wave_theta(const double* row, int d, do
 }
 
 // DBG: sections of a topic step timed by thread 0 of workgroup 0 (a worker) and of the last workgroup (RRI_ONCHIP_TIMING,
-// tools/onchip_probe.py): 0 phase A loads, 1 phase A rest + signal, 2 wait for the workers, 3 phase B loads, 4 row dots,
-// 5 W update, 6 carry, 7 hand-over to the workers
+// tools/onchip_probe.py): 0 wait for the carries + their load, 1 phase A rest, 2 next carry + wait for the workers, 3 marking the
+// consumed slots absent, 4 row dots, 5 W update, 6 carry_post, 7 to the top of the next step; with the projection: 8 closed
+// form, 10 slices arrive, 12 projected
 // PROJ: the instantiation for the topic-model flags (the projection stage costs the plain one registers it does not have)
 // KT: k-term dots take KT terms per lane of an 8-lane group: 3 for k <= 24, 8 for k <= 64 (same sums: the terms past k are zeros)
 template <typename SX, int RPW, bool DBG = false, bool PROJ = false, int KT = 3>

@@ -379,5 +379,5 @@ def test_row_sharded_call_is_checked_before_any_device_work():
                dict(eps_gauss_t=1.0, delta_gauss_t=0.1), dict(early_stop=lambda X, W, T: 0.0)):
         with pytest.raises(NotImplementedError):
             nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, group=grp, **kw)
-    with pytest.raises(NotImplementedError):
-        nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, fix_T=True, schedule='residual')
+    with pytest.raises(NotImplementedError):               # the weighted flavour always keeps its masked residual (fixed halves on a
+        nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, W_mat=np.ones_like(X), schedule='residual')     # residual handle run since round 3)

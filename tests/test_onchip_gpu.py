@@ -1,17 +1,19 @@
 """The register-resident persistent sweep (rri_onchip_kernels.hpp): launch-bound sizes whose fp32 X fits the chip's
-registers run rri_sweep as ONE launch with two hand-overs between workgroups per topic step.  Same arithmetic as the launch-per-phase
+registers run rri_sweep as ONE launch with two exchanges between workgroups per topic step (the data is its own hand-over).  Same arithmetic as the launch-per-phase
 kernels (nmf.py:437-476, 670-676, 728-734), another order of the partial sums:
 
   * against the launch-per-phase schedule (RRI_ONCHIP=0) on the same inputs: 1e-9, every wave layout (d <= 256 / 512 /
-    1024), ragged shapes, k = 2 and k = 22, regularisation, the c <= 0 branches with bounds;
+    1024 / 2048), ragged shapes, k = 2 ... 64, regularisation, the c <= 0 branches with bounds;
   * against the CPU oracle (the reference's operation order): 2e-9, BASELINE's 10000 x 1000, k = 20 included;
   * reset events of both kinds through nmf(): the same events at the same steps, the same result;
   * the topic-model flags (T rows projected onto the simplex at every step: one more hand-over among the workers), the
     one-hot branch of qf_min included;
   * float64 storage (half the rows per workgroup), the reference's vectors through it (the goldens of tests/golden run in
     float64: test_hip_parity.py / test_nmf_gpu.py take this path wherever the configuration allows);
-  * what the path does not cover (fixed halves, k > 22, too many rows for the registers) reports not eligible
-    and runs as before.
+  * k up to 64 and d up to 2048 (plain flags), compared from a warm start (the first sweeps of a long chain from a random start
+    are chaotic for any implementation: tools/onchip_large_k_check.py);
+  * what the path does not cover (fixed halves, k > 64, d > 1024 with a projection, too many rows for the registers) reports not
+    eligible and runs as before.
 """
 import os
 

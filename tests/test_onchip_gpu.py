@@ -434,8 +434,8 @@ def test_float64_storage(shape, flags):
 
 @pytest.mark.parametrize('flags', [dict(), TM])
 def test_same_bits_run_to_run(flags):
-    """every sum of the persistent kernel has a fixed order (no atomics, the flags only order the phases): two runs of the
-    same problem give the same bits, whatever the order in which workgroups arrive at the hand-overs"""
+    """every sum of the persistent kernel has a fixed order (no atomics; the polls only decide WHEN a value is used): two runs of
+    the same problem give the same bits, whatever the order in which the workgroups' values arrive"""
     n, d, k = 6000, 1000, 12
     X = planted_X(n, d, k, seed=111, dtype=np.float32)
     W0, T0 = scaled_init(X, k, seed=112)
@@ -443,3 +443,20 @@ def test_same_bits_run_to_run(flags):
     runs = [run(X, W0, T0, 7, True, **flags) for _ in range(3)]
     for Wr, Tr, _, _ in runs[1:]:
         assert np.array_equal(Wr, runs[0][0]) and np.array_equal(Tr, runs[0][1])
+
+
+@pytest.mark.parametrize('flags', [dict(), TM], ids=['plain', 'topic-model'])
+def test_naps_change_the_timing_of_the_polls_and_nothing_else(monkeypatch, flags):
+    """a wave sleeps through part of a wait it expects before it polls again (RRI_ONCHIP_NAP_EIGHTHS, OnchipNap): with the naps
+    off, at 3/8 and at 7/8 of the observed wait the same bits come out"""
+    n, d, k = 6000, 900, 12
+    X = planted_X(n, d, k, seed=91, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=92)
+    T0 = T0 / T0.sum(1, keepdims=True)
+    got = []
+    for eighths in ('0', '3', '7'):
+        monkeypatch.setenv('RRI_ONCHIP_NAP_EIGHTHS', eighths)
+        Wg, Tg, _, _ = run(X, W0, T0, 6, True, **flags)
+        got.append((Wg, Tg))
+    for Wg, Tg in got[1:]:
+        assert np.array_equal(Wg, got[0][0]) and np.array_equal(Tg, got[0][1])

@@ -171,7 +171,10 @@ rri_status rri_get_residual(rri_ctx* ctx, void* host, int64_t ld, int32_t host_d
 /* Row-wise simplex projection of W (proj_mat_to_simplex, matrixops.py:72-100; final
  * projection nmf.py:519-529).  s_vec == NULL: every row to the scalar s; else n doubles. */
 rri_status rri_project_W_rows(rri_ctx* ctx, double s, const double* s_vec);
-/* true_objective (nmf.py:71-94) with the handle's regularisers and mask; float64 accumulation. */
+/* true_objective (nmf.py:71-94) with the handle's regularisers and mask; float64 accumulation.  Right after rri_sweep on an
+ * unweighted handle no pass over X is made (1/2 ||X||^2 - sum_t <w_t, X t_t> + 1/2 <W^T W, T T^T>, the cross terms left by the
+ * sweep); after a sweep of the register-resident kernel nothing is launched at all -- the kernel left the value with the state
+ * the host reads anyway (RRI_ONCHIP_OBJ=0: the Gram kernels instead). */
 rri_status rri_objective(rri_ctx* ctx, double* out);
 /* argmax over topics of every row of W (harden_distributions, matrixops.py:203-209). */
 rri_status rri_argmax_rows(rri_ctx* ctx, int32_t* out_host);

@@ -200,6 +200,10 @@ struct rri_ctx {
     double* XYpart = nullptr;
     int xy_run = -1;
     bool xy_valid = false, x_sq_valid = false;
+    // the persistent sweep left the objective of the sweep that has just ended (minus 1/2 ||X||^2) in DevState.obj_track: pending
+    // while the launch is in flight, valid exactly as long as xy_valid is
+    bool obj_track_pending = false, obj_track_valid = false;
+    double obj_track_value = 0.0;
     double x_sq = 0.0;
     bool pending_wcheck = false;
     int pending_wcheck_topic = -1;
@@ -225,7 +229,7 @@ struct rri_ctx {
 
     // register-resident sweeps (rri_onchip_kernels.hpp): per-workgroup partial arrays and the grid barrier's counter
     int n_cu = 0;
-    double *mkZ = nullptr, *mkG = nullptr, *mkP = nullptr, *mkX = nullptr, *mkT = nullptr;
+    double *mkZ = nullptr, *mkG = nullptr, *mkP = nullptr, *mkX = nullptr, *mkT = nullptr, *objE = nullptr;
     unsigned* mkbar = nullptr;
     long onchip_launches = 0;
     // a persistent launch whose workgroups could not synchronise (HALT_ERR_GRID_SYNC: the device was shared, not every
@@ -429,6 +433,7 @@ int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_onchip = 1;       // RRI_ONCHIP=0: never the register-resident persistent sweep (rri_onchip_kernels.hpp)
+int g_onchip_obj = 1;   // RRI_ONCHIP_OBJ=0: the persistent sweep does not leave the objective of its last sweep (rri_objective takes the Gram kernels)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
 int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
 int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
@@ -783,6 +788,7 @@ struct LK {  // float64-only kernels
         if (t == 0) { c->xy_run = 1; c->xy_rows = rows; }
         else c->xy_run = (c->xy_run == t && c->xy_rows == rows) ? t + 1 : -1;
         c->xy_valid = c->xy_run == c->k;
+        c->obj_track_valid = false;
     }
     template <bool UPDATE, bool CARRY>
     static void wcol(rri_ctx* c, int t, int tn, int sweep) {
@@ -953,6 +959,7 @@ void invalidate(rri_ctx* c) {
     c->resid_valid = false;
     c->xy_run = -1;
     c->xy_valid = false;
+    c->obj_track_valid = false;
 }
 
 // ---- the topic-step scheduler ------------------------------------------------------------------
@@ -1012,6 +1019,7 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     c->resid_valid = false;
     c->q_valid = false;   // T changed
     c->xy_valid = false;  // a T row changed: complete again after the W half of topic k-1
+    c->obj_track_valid = false;
 }
 
 void enqueue_W_half(rri_ctx* c, int sweep, int t) {
@@ -1108,6 +1116,7 @@ void enqueue_rT_half(rri_ctx* c, int sweep, int t, bool standalone) {
     c->resid_fresh = false;
     c->dt_pending = true;     // told holds the previous row: R lacks w_t (T[t,:] - told)^T
     c->xy_valid = false;
+    c->obj_track_valid = false;
 }
 
 void enqueue_rW_half(rri_ctx* c, int sweep, int t) {
@@ -1349,7 +1358,7 @@ bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     g->kS = c->k | 1;                                  // odd row stride of the LDS copy of W: no bank conflicts down a column
     if (g->rpw > (c->dtype == RRI_F32 ? ONCHIP_MAX_RPW : ONCHIP_MAX_RPW / 2) || g->NA > 64 || g->NA > g->G || (i64)g->rows_wg * g->kS > 6144) return false;
     const size_t doubles = (size_t)g->rows_wg * g->kS + (size_t)c->k * ONCHIP_CWA + (c->k + 2) + (c->k + 1) +
-                           (size_t)ONCHIP_PG * ONCHIP_CWA + (size_t)g->CG * g->rows_wg + g->rows_wg +
+                           (size_t)ONCHIP_PG * ONCHIP_CWA + (size_t)g->CG * g->rows_wg + 2 * (size_t)g->rows_wg +
                            (size_t)ONCHIP_WAVES * 256 + (size_t)ONCHIP_WAVES * 8 * 72 + 1024 + 40;
     g->shmem = doubles * sizeof(double);
     return g->shmem <= 150 * 1024;
@@ -1422,18 +1431,19 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         if (hipMalloc((void**)&c->mkbar, (size_t)(128 + g.G) * sizeof(unsigned)) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkX, (size_t)2 * c->LD * 8) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkT, (size_t)2 * c->LD * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->objE, (size_t)256 * 8) != hipSuccess) return false;
         (void)hipMemsetAsync(c->mkZ, 0, (size_t)2 * g.G * c->LD * 8, c->stream);
         (void)hipMemsetAsync(c->mkG, 0, (size_t)2 * g.G * (k + 2) * 8, c->stream);
         (void)hipMemsetAsync(c->mkP, 0, (size_t)2 * 64 * (k + 1) * 8, c->stream);
     }
-    if (!c->mkG || !c->mkP || !c->mkbar || !c->mkX || !c->mkT) return false;
+    if (!c->mkG || !c->mkP || !c->mkbar || !c->mkX || !c->mkT || !c->objE) return false;
     if (!c->Wsafe && hipMalloc((void**)&c->Wsafe, (size_t)k * c->ldw * 8) != hipSuccess) { c->Wsafe = nullptr; return false; }
     if (!c->Tsafe && hipMalloc((void**)&c->Tsafe, (size_t)k * c->LD * 8) != hipSuccess) { c->Tsafe = nullptr; return false; }
     (void)hipMemsetAsync(c->mkbar, 0, (size_t)(128 + g.G) * sizeof(unsigned), c->stream);
     OnchipArgs a{};
     a.X = c->X; a.ldx = c->ldx; a.n = (int)c->n; a.d = (int)c->d; a.LD = (int)c->LD; a.k = k;
     a.Wt = c->W; a.ldw = c->ldw; a.T = c->T; a.ldt = c->LD;
-    a.mkZ = c->mkZ; a.mkG = c->mkG; a.mkP = c->mkP; a.mkX = c->mkX; a.mkT = c->mkT; a.xyp = c->XYpart; a.xy_stride = c->xy_stride; a.bar = c->mkbar;
+    a.mkZ = c->mkZ; a.mkG = c->mkG; a.mkP = c->mkP; a.mkX = c->mkX; a.mkT = c->mkT; a.objE = c->objE; a.xyp = c->XYpart; a.xy_stride = c->xy_stride; a.bar = c->mkbar;
     a.G = g.G; a.NA = g.NA; a.rows_wg = g.rows_wg; a.CG = g.CG; a.RG = g.RG; a.kS = g.kS;
     a.s0 = cur.sweep; a.t0 = cur.topic; a.ph0 = cur.phase; a.s_end = c->run_total;
     a.skip_row_finish = c->skip_row_finish ? 1 : 0;
@@ -1441,6 +1451,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     a.entry_spin_limit = 40000u;        // the hand-over at kernel entry: a grid that is not resident as a whole shows within ~40 ms
     if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = a.entry_spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
     if (const char* e = getenv("RRI_ONCHIP_ENTRY_SPIN_LIMIT")) a.entry_spin_limit = (unsigned)std::max(0, atoi(e));
+    // the last sweep of the launch runs from its topic 0: its objective can be left behind (see eacc in the kernel)
+    a.track = (g_onchip_obj && (c->run_total - 1 > cur.sweep || (cur.topic == 0 && cur.phase == 0))) ? 1 : 0;
     a.nap_eighths = 5;
     if (const char* e = getenv("RRI_ONCHIP_NAP_EIGHTHS")) a.nap_eighths = std::min(7, std::max(0, atoi(e)));      // diagnostics
     a.p = kparams(c); a.st = c->st;
@@ -1513,6 +1525,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     c->xy_run = whole_last ? k : -1;
     c->xy_rows = g.G;
     c->xy_valid = whole_last;
+    c->obj_track_valid = false;
+    c->obj_track_pending = a.track != 0;
     return true;
 }
 
@@ -1637,7 +1651,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     // the switches are per process and read again by every rri_create: an unset variable means the default, not "what
     // the last handle was created with"
     g_pass_unroll = 8; g_pass_unroll_upd = 16; g_pass_nt = -1; g_pass_rs = 1; g_obj_direct = 0; g_pass_interleave = -1;
-    g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_wpass_il = -1;
+    g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_onchip_obj = 1; g_wpass_il = -1;
     g_wpass_uc = 8;
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;
@@ -1648,6 +1662,7 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_RESID_MFMA")) g_resid_mfma = atoi(e) != 0;
     if (const char* e = getenv("RRI_SIDE_JOBS")) g_side_jobs = atoi(e) != 0;
     if (const char* e = getenv("RRI_ONCHIP")) g_onchip = atoi(e) != 0;
+    if (const char* e = getenv("RRI_ONCHIP_OBJ")) g_onchip_obj = atoi(e) != 0;
     g_onchip_coop = 0;
     g_pass_rot = 0;
     if (const char* e = getenv("RRI_PASS_ROT")) g_pass_rot = atoi(e) & 7;
@@ -1817,7 +1832,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -2187,6 +2202,7 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
 static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done) {
     HIPCHK(c, hipSetDevice(c->device));
     c->onchip_in_flight = false;
+    c->obj_track_pending = false;
     enqueue_from(c, from);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(c, RRI_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
@@ -2219,6 +2235,11 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
         r = read_state(c, &s);
         if (r != RRI_OK) return r;
     }
+    if (c->onchip_in_flight && c->obj_track_pending && s.halt == 0 && c->xy_valid) {
+        c->obj_track_value = s.obj_track;       // came with the state read above: no kernel, no second trip for rri_objective
+        c->obj_track_valid = true;
+    }
+    c->obj_track_pending = false;
     c->onchip_in_flight = false;
     return status_from_halt(c, s, sweeps_done);
 }
@@ -2409,6 +2430,20 @@ static rri_status norms_of(rri_ctx* c, const double* A, i64 rows, i64 cols, i64 
 
 // out = {data term, ||W||^2, ||W||_1}; tn (optional) = {., ||T||^2, ||T||_1}: everything rri_objective needs, with
 // ONE synchronisation on the path taken after a complete sweep
+// ||X||^2, once per X (the constant of the objective's Gram form)
+static rri_status ensure_x_sq(rri_ctx* c) {
+    if (c->x_sq_valid) return RRI_OK;
+    DISPATCH(c, hipLaunchKernelGGL((k_sqsum<typename L::Elem>), dim3(256), dim3(256), 0, c->stream,
+                                   (const typename L::Elem*)c->X, c->ldx, c->n, c->d, c->normpart));
+    double h[256];
+    HIPCHK(c, hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->x_sq = 0.0;
+    for (int b = 0; b < 256; ++b) c->x_sq += h[b];
+    c->x_sq_valid = true;
+    return RRI_OK;
+}
+
 static rri_status objective_terms(rri_ctx* c, double out[3], double* tn) {
     CHECK_CTX(c);
     if (!c->have_X || !c->have_W || !c->have_T) return fail(c, RRI_ERR_INVALID, "X, W, T must be set");
@@ -2431,16 +2466,8 @@ static rri_status objective_terms(rri_ctx* c, double out[3], double* tn) {
         // The terms are of the size of ||X||^2: the result carries an absolute error of a few ulp of that
         // (relative 1e-11 at a residual of 0.5 %), far below what the stop rule of nmf.py:510 resolves.
         const int k = c->k;
-        if (!c->x_sq_valid) {
-            DISPATCH(c, hipLaunchKernelGGL((k_sqsum<typename L::Elem>), dim3(256), dim3(256), 0, c->stream,
-                                           (const typename L::Elem*)c->X, c->ldx, c->n, c->d, c->normpart));
-            double h[256];
-            HIPCHK(c, hipMemcpyAsync(h, c->normpart, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->x_sq = 0.0;
-            for (int b = 0; b < 256; ++b) c->x_sq += h[b];
-            c->x_sq_valid = true;
-        }
+        rri_status rx = ensure_x_sq(c);
+        if (rx != RRI_OK) return rx;
         double* gw = c->objbuf;
         double* gt = gw + k * k;
         double* xy = gt + k * k;
@@ -2506,6 +2533,15 @@ rri_status rri_objective_parts(rri_ctx* c, double out[3]) { return objective_ter
 rri_status rri_objective(rri_ctx* c, double* out) {
     CHECK_CTX(c);
     if (!out) return fail(c, RRI_ERR_INVALID, "out is NULL");
+    if (c->obj_track_valid && c->xy_valid && !c->weighted && !c->comm && !g_obj_direct) {
+        // the persistent sweep that has just ended left its objective (all terms but the constant): nothing to launch
+        if (!c->have_X || !c->have_W || !c->have_T) return fail(c, RRI_ERR_INVALID, "X, W, T must be set");
+        HIPCHK(c, hipSetDevice(c->device));
+        rri_status rx = ensure_x_sq(c);
+        if (rx != RRI_OK) return rx;
+        *out = 0.5 * c->x_sq + c->obj_track_value;
+        return RRI_OK;
+    }
     double parts[3], nt[3];
     rri_status r = objective_terms(c, parts, nt);
     if (r != RRI_OK) return r;

@@ -48,6 +48,7 @@ struct DevState {
     double nt;       // ||T[t,:]||^2
     double sumT;
     double theta;
+    double obj_track;   // the persistent sweep: objective of the launch's last sweep minus 1/2 ||X||^2 (OnchipArgs.track)
 };
 
 struct KParams {

@@ -66,6 +66,8 @@ struct OnchipArgs {
     double* mkX;                   // [2][LD]  the T row before its projection (topic-model flags): slices from the workers, by the
                                    // parity of the step; an element that has not arrived holds ONCHIP_ABSENT
     double* xyp; int xy_stride;    // <w_t, X t_t> partials for the objective (XYpart[t * xy_stride + b])
+    double* objE;                  // [G]  exchange slots: every workgroup's share of the objective of the LAST sweep of the launch
+    int track;                     // 1: the kernel leaves that objective (without the constant 1/2 ||X||^2) in DevState.obj_track
     unsigned* bar;                 // [0] abort word, [128 + b] the entry flag of workgroup b (zero at launch)
     int G, NA, rows_wg, CG, RG, kS;
     int s0, t0, ph0, s_end;        // cursor (sweep, topic, phase) and end sweep (exclusive)
@@ -355,7 +357,8 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     double* zred = tts + k + 1;                             // [PG][CWA]       partial column sums of a worker
     double* ysh = zred + PG * CWA;                          // [CG][rows_wg]
     double* xyl = ysh + (size_t)CG * a.rows_wg;             // [rows_wg]
-    double* zsh = xyl + a.rows_wg;                          // [RG][CG * 256] = 8 x 256
+    double* qyl = xyl + a.rows_wg;                          // [rows_wg]  a row's share of the objective's W-side terms of the step
+    double* zsh = qyl + a.rows_wg;                          // [RG][CG * 256] = 8 x 256
     double* tiles = zsh + NWV * 256;                        // [8 waves][8 x 72]   row-sum tiles (wave_rowsum8)
     const int LDp = CG * 256;
     double* tile = tiles + wave * (8 * 72);
@@ -476,6 +479,14 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     };
     bool have_carry = false;
     OnchipNap napA, napB;          // this wave's waits for the carries (workers) / for the workers
+    // The objective of a sweep without a pass over X or a Gram kernel afterwards (nmf() asks for it after every sweep,
+    // nmf.py:488-490, 510): 1/2 ||X - W T||^2 = 1/2 ||X||^2 - sum_t <w_t, X t_t> + 1/2 <W^T W, T T^T>, and with A = W^T W,
+    // B = T T^T of the END of the sweep, 1/2 <A, B> = sum_t (sum_{l<t} A_tl B_tl + 1/2 A_tt B_tt): at step t the columns l < t
+    // of W and the rows l <= t of T are final, B_tl is what every workgroup holds in tts[l], and A_tl is a sum over rows -- so a
+    // ROW's share of step t is w_it (-y_i + sum_{l<t} B_tl w_il + 1/2 B_tt w_it) (+ its share of the penalties), one more
+    // masked k-term dot next to the one the update needs.  eacc: this workgroup's sum over the steps of the running sweep
+    // (wave 1; workgroup 0 adds the T-side penalties), stored at the end of the launch's last sweep.
+    double eacc = 0.0;
     int chk = 0, tprev = -1;
     unsigned stepq = 0;       // topic steps of this launch so far
 
@@ -487,6 +498,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // Every exchange slot this workgroup owns starts "absent", in both buffers.
     for (int e = tid; e < 2 * a.LD; e += NTH) st_agent(a.mkZ + (size_t)(e / a.LD) * G * a.LD + (unsigned)(b * a.LD + e % a.LD), onchip_absent_value());
     if (tid < 2 * (k + 2)) st_agent(a.mkG + (size_t)(tid / (k + 2)) * (k + 2) * G + (unsigned)((tid % (k + 2)) * G + b), onchip_absent_value());
+    if (a.track && tid == NTH - 1) st_agent(a.objE + (unsigned)b, onchip_absent_value());
     if (worker) {
         if (tid < 2 * CWA) {
             const int which = tid / CWA, jl = tid % CWA;
@@ -820,7 +832,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 for (int r0 = 0; r0 < rows_here; r0 += NTH / 8) {
                     const int i = r0 + (tid >> 3), sub = tid & 7;
                     constexpr int TERMS = KT;
-                    double part = 0.0, y = 0.0;
+                    double part = 0.0, part_lt = 0.0, y = 0.0;
                     if (i < rows_here) {
                         double wv[TERMS], sv[TERMS];
 #pragma unroll
@@ -832,8 +844,11 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         if (sub < CG) y = ysh[(size_t)sub * a.rows_wg + i];
 #pragma unroll
                         for (int q = 0; q < TERMS; ++q) part = fma(wv[q], sv[q], part);
+#pragma unroll
+                        for (int q = 0; q < TERMS; ++q) part_lt = fma(wv[q], (sub + 8 * q < t) ? sv[q] : 0.0, part_lt);
                     }
                     part = group8_sum(part);
+                    part_lt = group8_sum(part_lt);
                     y = group8_sum(y);                                           // CG <= 8 partials, in lanes 0 .. CG - 1
                     if (i < rows_here && sub == 0) {
                         const double numer = (y - part) - p.reg_w_l1;
@@ -843,6 +858,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         Wl[(size_t)i * kS + t] = wnew;
                         a.Wt[(i64)t * a.ldw + row0 + i] = wnew;
                         xyl[i] = wnew * y;
+                        qyl[i] = wnew * (part_lt + 0.5 * tts[t] * wnew + 0.5 * p.reg_w_l2 * wnew + p.reg_w_l1);
                     }
                 }
                 onchip_stores_landed();                    // the "absent" marks above (and a worker's of phase A) before carry_post
@@ -853,6 +869,15 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     for (int i = lane; i < rows_here; i += 64) acc += xyl[i];
                     acc = wave_sum<double>(acc);
                     if (lane == 0) a.xyp[(i64)t * a.xy_stride + b] = acc;
+                } else if (wave == 1 && a.track) {         // this step's share of the objective (see eacc)
+                    double acc = 0.0;
+#pragma unroll 1
+                    for (int i = lane; i < rows_here; i += 64) acc += qyl[i] - xyl[i];
+                    acc = wave_sum<double>(acc);
+                    if (t == 0) eacc = 0.0;
+                    eacc += acc;
+                    if (b == 0) eacc += 0.5 * p.reg_t_l2 * tts[t] + p.reg_t_l1 * tts[k];
+                    if (last_step && lane == 0) st_data(a.objE + (unsigned)b, eacc);
                 }
                 RRI_STAMP(5);
                 carry_post((t + 1) % k, t, buf ^ 1);
@@ -885,6 +910,17 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 st->halt_topic = tprev; st->halt_sweep = a.s_end; st->halt_pos = 0;
             }
         }
+    }
+    // the objective of the launch's last sweep (minus the constant 1/2 ||X||^2): the workgroups' shares, polled like everything
+    // else that crosses workgroups, added in workgroup order
+    if (a.track && chk && b == 0) {
+        double es[4];
+        auto eoff = [&](int u, int z) -> unsigned { return lane + z + 64 * u < G ? (unsigned)(lane + z + 64 * u) : ONCHIP_NONE; };
+        onchip_poll_issue<4>(a.objE, eoff, es);
+        const int failed = onchip_poll_finish<4>(a.objE, eoff, es, a.bar, a.spin_limit);
+        if (__syncthreads_or(failed)) goto sync_failed;
+        const double v = wave_sum<double>(((es[0] + es[1]) + es[2]) + es[3]);
+        if (tid == 0) st->obj_track = v;
     }
     return;
 sync_failed:

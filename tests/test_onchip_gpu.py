@@ -460,3 +460,33 @@ def test_naps_change_the_timing_of_the_polls_and_nothing_else(monkeypatch, flags
         got.append((Wg, Tg))
     for Wg, Tg in got[1:]:
         assert np.array_equal(Wg, got[0][0]) and np.array_equal(Tg, got[0][1])
+
+@pytest.mark.parametrize('flags', [dict(), dict(reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03), TM],
+                         ids=['plain', 'regularised', 'topic-model'])
+def test_the_objective_the_persistent_sweep_leaves_behind(monkeypatch, flags):
+    """nmf() asks for the objective after every sweep (nmf.py:488-490, 510).  The persistent kernel accumulates it on the way --
+    a row's share of step t is w_it (-y_i + sum_{l<t} (T T^T)_tl w_il + 1/2 (T T^T)_tt w_it) plus its penalties -- and leaves
+    it with the state the host reads anyway: rri_objective launches nothing.  Against the Gram kernels of the other path
+    (RRI_ONCHIP_OBJ=0) and against 1/2 ||X - W T||^2 taken through the residual (RRI_OBJ_DIRECT=1)"""
+    n, d, k = 4000, 900, 9
+    X = planted_X(n, d, k, seed=131, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=132)
+    T0 = T0 / T0.sum(1, keepdims=True)
+    got = {}
+    for name, env in (('tracked', {}), ('gram', {'RRI_ONCHIP_OBJ': '0'}), ('direct', {'RRI_OBJ_DIRECT': '1'})):
+        for key in ('RRI_ONCHIP_OBJ', 'RRI_OBJ_DIRECT'):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        Wg, Tg, objs, _ = run(X, W0, T0, 5, True, objective=True, **flags)
+        with onchip(True), engine(n, d, k, dtype=np.float32) as e:          # and after a launch of several sweeps
+            e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+            e.sweep(5)
+            got[name] = (Wg, Tg, objs, e.objective())
+    for name in ('gram', 'direct'):
+        assert np.array_equal(got[name][0], got['tracked'][0]) and np.array_equal(got[name][1], got['tracked'][1])
+        rel = np.abs(got['tracked'][2] - got[name][2]) / np.abs(got[name][2])
+        print('objective left by the kernel vs %s: %s' % (name, ' '.join('%.1e' % r for r in rel)))
+        assert rel.max() < 1e-9, (name, rel)
+        assert abs(got['tracked'][3] - got[name][3]) < 1e-9 * abs(got[name][3])
+        assert abs(got['tracked'][3] - got['tracked'][2][-1]) < 1e-12 * abs(got['tracked'][3])      # 5 sweeps in one launch or in five

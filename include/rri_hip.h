@@ -295,6 +295,17 @@ rri_status rri_onchip_info(rri_ctx* ctx, int32_t* eligible, int64_t* launches);
  * scheduling (nmf.py:415-476): it completes -- W and T are put back to what they were before the launch and the same steps
  * run on the launch-per-phase schedule, which the handle then keeps.  *fallbacks: how often that happened on this handle. */
 rri_status rri_onchip_fallbacks(rri_ctx* ctx, int64_t* fallbacks);
+/* The sweep / objective / stop-rule loop of nmf.py:377-516 for launch-bound sizes, in one call: up to n_sweeps sweeps of the
+ * register-resident kernel with the objective of every sweep kept (true_objective, nmf.py:71-94, 488-490) and the rule of
+ * nmf.py:510 / optimization.py:284-291 applied ON THE DEVICE after every sweep: the run ends after the first sweep s with
+ * |o_s - o_(s-1)| <= stop_scale, where o_(-1) = obj_prev and the caller passes stop_scale = eps_stop |o_0 - o_1| of its run
+ * (a negative stop_scale never stops).  *sweeps_done sweeps have run; obj_hist (room for n_sweeps doubles) holds their
+ * objectives, NaN where the kernel left none -- the sweep an event interrupted (the call ends with that sweep once the event
+ * is resolved and rri_resume has finished it) or a sweep run on the launch-per-phase schedule after a fallback (the call then
+ * ends after one sweep): take rri_objective there.  RRI_ERR_UNSUPPORTED when the handle does not take the persistent
+ * path (rri_onchip_info) or n_sweeps > 512: call rri_sweep / rri_objective sweep by sweep. */
+rri_status rri_sweep_until(rri_ctx* ctx, int32_t n_sweeps, double obj_prev, double stop_scale, double* obj_hist,
+                           int32_t* sweeps_done);
 /* Stand-alone kernels for roofline measurement (bench.py): R <- R - a b^T fused with the
  * next residual products, on a scratch copy of X, with the handle's own W[:,0], T[0,:] as factors. */
 rri_status rri_bench_rank1_update(rri_ctx* ctx, int32_t reps, double* avg_ms);

@@ -204,6 +204,9 @@ struct rri_ctx {
     // while the launch is in flight, valid exactly as long as xy_valid is
     bool obj_track_pending = false, obj_track_valid = false;
     double obj_track_value = 0.0;
+    // rri_sweep_until: sweeps with the objective history kept and the stop rule applied on the device (persistent sweep only)
+    struct { bool active = false; double prev = 0.0, scale = 0.0; int n = 0; double* out = nullptr; } until;
+    double *objhist = nullptr, *objdec = nullptr;
     double x_sq = 0.0;
     bool pending_wcheck = false;
     int pending_wcheck_topic = -1;
@@ -1345,6 +1348,7 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
 
 // ---- register-resident persistent sweeps (rri_onchip_kernels.hpp) ---------------------------------------------
 struct OnchipGeom { int CG, RG, rows_wg, rpw, NA, kS, G; size_t shmem; };
+constexpr int ONCHIP_UNTIL_CAP = 512;   // sweeps per launch of rri_sweep_until (a slot row of 256 shares each)
 constexpr int ONCHIP_MAX_RPW = 20;    // rows per wave held in registers (float4 each): 32 spills at 256 VGPRs
 bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     const bool proj = !LK::light(c);                   // the projection stage stages the whole T row per worker: d <= 1024
@@ -1431,12 +1435,14 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         if (hipMalloc((void**)&c->mkbar, (size_t)(128 + g.G) * sizeof(unsigned)) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkX, (size_t)2 * c->LD * 8) != hipSuccess) return false;
         if (hipMalloc((void**)&c->mkT, (size_t)2 * c->LD * 8) != hipSuccess) return false;
-        if (hipMalloc((void**)&c->objE, (size_t)256 * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->objE, (size_t)ONCHIP_UNTIL_CAP * 256 * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->objhist, (size_t)ONCHIP_UNTIL_CAP * 8) != hipSuccess) return false;
+        if (hipMalloc((void**)&c->objdec, (size_t)ONCHIP_UNTIL_CAP * 8) != hipSuccess) return false;
         (void)hipMemsetAsync(c->mkZ, 0, (size_t)2 * g.G * c->LD * 8, c->stream);
         (void)hipMemsetAsync(c->mkG, 0, (size_t)2 * g.G * (k + 2) * 8, c->stream);
         (void)hipMemsetAsync(c->mkP, 0, (size_t)2 * 64 * (k + 1) * 8, c->stream);
     }
-    if (!c->mkG || !c->mkP || !c->mkbar || !c->mkX || !c->mkT || !c->objE) return false;
+    if (!c->mkG || !c->mkP || !c->mkbar || !c->mkX || !c->mkT || !c->objE || !c->objhist || !c->objdec) return false;
     if (!c->Wsafe && hipMalloc((void**)&c->Wsafe, (size_t)k * c->ldw * 8) != hipSuccess) { c->Wsafe = nullptr; return false; }
     if (!c->Tsafe && hipMalloc((void**)&c->Tsafe, (size_t)k * c->LD * 8) != hipSuccess) { c->Tsafe = nullptr; return false; }
     (void)hipMemsetAsync(c->mkbar, 0, (size_t)(128 + g.G) * sizeof(unsigned), c->stream);
@@ -1453,6 +1459,13 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     if (const char* e = getenv("RRI_ONCHIP_ENTRY_SPIN_LIMIT")) a.entry_spin_limit = (unsigned)std::max(0, atoi(e));
     // the last sweep of the launch runs from its topic 0: its objective can be left behind (see eacc in the kernel)
     a.track = (g_onchip_obj && (c->run_total - 1 > cur.sweep || (cur.topic == 0 && cur.phase == 0))) ? 1 : 0;
+    if (c->until.active && cur.topic == 0 && cur.phase == 0 && c->run_total - cur.sweep <= ONCHIP_UNTIL_CAP && c->x_sq_valid) {
+        a.track = 2;
+        a.objhist = c->objhist; a.dec = c->objdec;
+        a.obj_prev = c->until.prev; a.stop_scale = c->until.scale; a.half_xsq = 0.5 * c->x_sq;
+        // "not written" = NaN: the sweeps of the call whose objective the kernel did not leave are told by that
+        (void)hipMemsetAsync(c->objhist, 0xFF, (size_t)(c->run_total - cur.sweep) * 8, c->stream);
+    }
     a.nap_eighths = 5;
     if (const char* e = getenv("RRI_ONCHIP_NAP_EIGHTHS")) a.nap_eighths = std::min(7, std::max(0, atoi(e)));      // diagnostics
     a.p = kparams(c); a.st = c->st;
@@ -1539,6 +1552,9 @@ void enqueue_final_check(rri_ctx* c, int sweep_arg) {
 
 void enqueue_from(rri_ctx* c, Cursor cur) {
     if (cur.sweep < c->run_total && onchip_ok(c) && enqueue_onchip(c, cur)) return;
+    // rri_sweep_until without the persistent kernel: nobody applies the stop rule between the sweeps, so the call ends after
+    // the sweep it is in and the caller decides
+    if (c->until.active && cur.sweep < c->run_total) c->run_total = cur.sweep + 1;
     enqueue_range(c, cur, c->run_total);
     enqueue_final_check(c, c->run_total);
 }
@@ -1564,7 +1580,15 @@ rri_status status_from_halt(rri_ctx* c, const DevState& s, int32_t* sweeps_done)
     }
     invalidate(c);
     c->pending_wcheck = false;
+    if (s.halt == HALT_EVENT_STOP) {      // rri_sweep_until: the stop rule held after sweep halt_sweep - 1; nothing of the next one is stored
+        c->paused = false;
+        if (sweeps_done) *sweeps_done = s.halt_sweep;
+        return RRI_OK;
+    }
     if (s.halt > 0) {
+        // rri_sweep_until: an event ends the call with the sweep it interrupts (position 0: the column check of the sweep before
+        // -- nothing of sweep halt_sweep has begun); that sweep's objective is the caller's to take after the event is resolved
+        if (c->until.active) c->run_total = std::min(c->run_total, (s.halt == HALT_EVENT_RESET_W && s.halt_pos == 0) ? s.halt_sweep : s.halt_sweep + 1);
         c->paused = true;
         c->pending.kind = s.halt == HALT_EVENT_RESET_T ? RRI_EVENT_RESET_T : RRI_EVENT_RESET_W;
         c->pending.topic = s.halt_topic;
@@ -1832,7 +1856,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -2228,6 +2252,7 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
         c->skip_row_finish = c->onchip_saved_skip;
         r = clear_halt(c);
         if (r != RRI_OK) return r;
+        if (c->until.active) c->run_total = std::min(c->run_total, from.sweep + 1);     // no stop rule on this schedule: one sweep, then the caller
         enqueue_range(c, from, c->run_total);
         enqueue_final_check(c, c->run_total);
         le = hipGetLastError();
@@ -2250,10 +2275,49 @@ rri_status rri_sweep(rri_ctx* c, int32_t n_sweeps, int32_t* sweeps_done) {
     if (r != RRI_OK) return r;
     if (c->paused) return fail(c, RRI_ERR_INVALID, "a paused run is pending: resolve the event and call rri_resume");
     if (n_sweeps < 0) return fail(c, RRI_ERR_INVALID, "n_sweeps < 0");
+    c->until.active = false;
     c->run_total = n_sweeps;
     r = clear_halt(c);
     if (r != RRI_OK) return r;
     return run_and_collect(c, Cursor{0, 0, 0}, sweeps_done);
+}
+
+static rri_status ensure_x_sq(rri_ctx* c);
+// the objective history of a finished rri_sweep_until call: what the kernel left (NaN where it left nothing)
+static rri_status until_finish(rri_ctx* c, rri_status r, const int32_t* sweeps_done) {
+    if (!c->until.active || r == RRI_PAUSED) return r;
+    c->until.active = false;
+    if (r != RRI_OK || !c->until.out) return r;
+    const int done = sweeps_done ? std::min(std::max(*sweeps_done, 0), c->until.n) : 0;
+    for (int i = 0; i < c->until.n; ++i) c->until.out[i] = std::nan("");
+    if (done > 0 && c->objhist && c->onchip_launches > 0) {
+        hipError_t e = hipMemcpyAsync(c->until.out, c->objhist, (size_t)done * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "objective history: %s", hipGetErrorString(e));
+    }
+    return r;
+}
+
+rri_status rri_sweep_until(rri_ctx* c, int32_t n_sweeps, double obj_prev, double stop_scale, double* obj_hist, int32_t* sweeps_done) {
+    CHECK_CTX(c);
+    rri_status r = ready(c);
+    if (r != RRI_OK) return r;
+    if (c->paused) return fail(c, RRI_ERR_INVALID, "a paused run is pending: resolve the event and call rri_resume");
+    if (n_sweeps < 1 || !obj_hist || !sweeps_done) return fail(c, RRI_ERR_INVALID, "n_sweeps < 1, or no place for the history / the count");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!onchip_ok(c) || n_sweeps > ONCHIP_UNTIL_CAP || !g_onchip_obj)
+        return fail(c, RRI_ERR_UNSUPPORTED, "rri_sweep_until needs the register-resident sweep (rri_onchip_info) and at most %d sweeps", ONCHIP_UNTIL_CAP);
+    r = ensure_x_sq(c);
+    if (r != RRI_OK) return r;
+    // the slots of the history the kernel writes must read "nothing" if no persistent launch of this call wrote them
+    if (c->objhist) HIPCHK(c, hipMemsetAsync(c->objhist, 0xFF, (size_t)n_sweeps * 8, c->stream));
+    c->until.active = true; c->until.prev = obj_prev; c->until.scale = stop_scale; c->until.n = n_sweeps; c->until.out = obj_hist;
+    c->run_total = n_sweeps;
+    r = clear_halt(c);
+    if (r != RRI_OK) { c->until.active = false; return r; }
+    r = run_and_collect(c, Cursor{0, 0, 0}, sweeps_done);
+    if (r != RRI_OK && r != RRI_PAUSED) c->until.active = false;
+    return until_finish(c, r, sweeps_done);
 }
 
 rri_status rri_resume(rri_ctx* c, int32_t* sweeps_done) {
@@ -2263,7 +2327,10 @@ rri_status rri_resume(rri_ctx* c, int32_t* sweeps_done) {
     c->paused = false;
     rri_status r = clear_halt(c);
     if (r != RRI_OK) return r;
-    return run_and_collect(c, c->resume_at, sweeps_done);
+    int32_t done_local = 0;
+    r = run_and_collect(c, c->resume_at, sweeps_done ? sweeps_done : &done_local);
+    if (r != RRI_OK && r != RRI_PAUSED) c->until.active = false;
+    return until_finish(c, r, sweeps_done ? sweeps_done : &done_local);
 }
 
 rri_status rri_pending_event(rri_ctx* c, rri_event* ev) {

@@ -32,6 +32,7 @@
 namespace rri {
 
 enum { HALT_EVENT_RESET_T = 1, HALT_EVENT_RESET_W = 2,
+       HALT_EVENT_STOP = 3,    // the persistent sweep: the stop rule of nmf.py:510 held at the end of sweep halt_sweep - 1
        HALT_ERR_UNBOUNDED = -4, HALT_ERR_W_COL_ZERO = -5, HALT_ERR_NOT_IMPLEMENTED = -6 };
 enum { RESET_NONE = 0, RESET_MAX_RESID = 1, RESET_RANDOM = 2 };
 

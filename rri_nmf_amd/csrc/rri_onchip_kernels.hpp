@@ -66,8 +66,15 @@ struct OnchipArgs {
     double* mkX;                   // [2][LD]  the T row before its projection (topic-model flags): slices from the workers, by the
                                    // parity of the step; an element that has not arrived holds ONCHIP_ABSENT
     double* xyp; int xy_stride;    // <w_t, X t_t> partials for the objective (XYpart[t * xy_stride + b])
-    double* objE;                  // [G]  exchange slots: every workgroup's share of the objective of the LAST sweep of the launch
-    int track;                     // 1: the kernel leaves that objective (without the constant 1/2 ||X||^2) in DevState.obj_track
+    double* objE;                  // [slots][G]  exchange slots: every workgroup's share of the objective of a sweep
+    int track;                     // 1: the objective of the launch's LAST sweep (slot 0), without the constant 1/2 ||X||^2, is
+                                   //    left in DevState.obj_track
+                                   // 2: also every sweep's objective in objhist[sweep - s0] (slot sweep - s0), and the stop rule
+                                   //    of nmf.py:510 / optimization.py:284-291 after every sweep but the last: a launch that
+                                   //    finds |o_s - o_{s-1}| <= stop_scale ends there (HALT_EVENT_STOP, halt_sweep = s + 1)
+    double* objhist;               // [sweeps of the launch]  (track == 2)
+    double* dec;                   // [sweeps of the launch]  exchange slots: workgroup 0's verdict after sweep s0 + i (0 go on, 1 stop)
+    double obj_prev, stop_scale, half_xsq;     // the objective before the launch, eps_stop |o_0 - o_1|, 1/2 ||X||^2
     unsigned* bar;                 // [0] abort word, [128 + b] the entry flag of workgroup b (zero at launch)
     int G, NA, rows_wg, CG, RG, kS;
     int s0, t0, ph0, s_end;        // cursor (sweep, topic, phase) and end sweep (exclusive)
@@ -487,6 +494,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // masked k-term dot next to the one the update needs.  eacc: this workgroup's sum over the steps of the running sweep
     // (wave 1; workgroup 0 adds the T-side penalties), stored at the end of the launch's last sweep.
     double eacc = 0.0;
+    double obj_before = a.obj_prev;      // workgroup 0: the objective of the sweep before the one that has just ended
     int chk = 0, tprev = -1;
     unsigned stepq = 0;       // topic steps of this launch so far
 
@@ -498,7 +506,12 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // Every exchange slot this workgroup owns starts "absent", in both buffers.
     for (int e = tid; e < 2 * a.LD; e += NTH) st_agent(a.mkZ + (size_t)(e / a.LD) * G * a.LD + (unsigned)(b * a.LD + e % a.LD), onchip_absent_value());
     if (tid < 2 * (k + 2)) st_agent(a.mkG + (size_t)(tid / (k + 2)) * (k + 2) * G + (unsigned)((tid % (k + 2)) * G + b), onchip_absent_value());
-    if (a.track && tid == NTH - 1) st_agent(a.objE + (unsigned)b, onchip_absent_value());
+    if (a.track == 1 && tid == NTH - 1) st_agent(a.objE + (unsigned)b, onchip_absent_value());
+    if (a.track == 2)
+        for (int i = tid; i < a.s_end - a.s0; i += NTH) {
+            st_agent(a.objE + (unsigned)(i * G + b), onchip_absent_value());
+            if (b == 0) st_agent(a.dec + (unsigned)i, onchip_absent_value());
+        }
     if (worker) {
         if (tid < 2 * CWA) {
             const int which = tid / CWA, jl = tid % CWA;
@@ -583,6 +596,36 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         if (mode < 0) {
                             code = mode;
                             if (b == 0 && tid == 0) { st->halt = code; st->halt_topic = t; st->halt_sweep = s; st->halt_pos = t; }
+                        }
+                    }
+                    if (a.track == 2 && t == 0 && s > a.s0 && code == 0) {
+                        // A sweep has just ended (its last column check passed above): workgroup 0 adds up its objective, applies
+                        // the stop rule and tells the other workers, which hold their T row back until they know.  "Stop" ends
+                        // the launch like any event -- nothing of sweep s has been stored for good.
+                        const int slot = s - 1 - a.s0;
+                        double es[4];
+                        const double* src = b == 0 ? a.objE + (size_t)slot * G : a.dec + slot;
+                        const int cnt = b == 0 ? G : 1;
+                        auto eoff = [&](int u, int z) -> unsigned { return lane + z + 64 * u < cnt ? (unsigned)(lane + z + 64 * u) : ONCHIP_NONE; };
+                        onchip_poll_issue<4>(src, eoff, es);
+                        const int efailed = onchip_poll_finish<4>(src, eoff, es, a.bar, a.spin_limit);
+                        if (__syncthreads_or(efailed)) goto sync_failed;
+                        const double ev = wave_sum<double>(((es[0] + es[1]) + es[2]) + es[3]);
+                        bool stop;
+                        if (b == 0) {
+                            const double obj = a.half_xsq + ev;
+                            stop = fabs(obj - obj_before) <= a.stop_scale;
+                            obj_before = obj;
+                            if (tid == 0) {
+                                a.objhist[slot] = obj;
+                                st_data(a.dec + slot, stop ? 1.0 : 0.0);
+                            }
+                        } else {
+                            stop = ev != 0.0;
+                        }
+                        if (stop) {
+                            code = HALT_EVENT_STOP;
+                            if (b == 0 && tid == 0) { st->halt = code; st->halt_topic = -1; st->halt_sweep = s; st->halt_pos = 0; }
                         }
                     }
                     if (code != 0) halt_bit = 0x80000000u;     // every worker takes the same verdict from the same sums
@@ -877,7 +920,8 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     if (t == 0) eacc = 0.0;
                     eacc += acc;
                     if (b == 0) eacc += 0.5 * p.reg_t_l2 * tts[t] + p.reg_t_l1 * tts[k];
-                    if (last_step && lane == 0) st_data(a.objE + (unsigned)b, eacc);
+                    if (t == k - 1 && lane == 0 && (a.track == 2 || last_step))
+                        st_data(a.objE + (unsigned)((a.track == 2 ? (s - a.s0) * G : 0) + b), eacc);
                 }
                 RRI_STAMP(5);
                 carry_post((t + 1) % k, t, buf ^ 1);
@@ -915,12 +959,17 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // else that crosses workgroups, added in workgroup order
     if (a.track && chk && b == 0) {
         double es[4];
+        const int slot = a.track == 2 ? a.s_end - 1 - a.s0 : 0;
+        const double* src = a.objE + (size_t)slot * G;
         auto eoff = [&](int u, int z) -> unsigned { return lane + z + 64 * u < G ? (unsigned)(lane + z + 64 * u) : ONCHIP_NONE; };
-        onchip_poll_issue<4>(a.objE, eoff, es);
-        const int failed = onchip_poll_finish<4>(a.objE, eoff, es, a.bar, a.spin_limit);
+        onchip_poll_issue<4>(src, eoff, es);
+        const int failed = onchip_poll_finish<4>(src, eoff, es, a.bar, a.spin_limit);
         if (__syncthreads_or(failed)) goto sync_failed;
         const double v = wave_sum<double>(((es[0] + es[1]) + es[2]) + es[3]);
-        if (tid == 0) st->obj_track = v;
+        if (tid == 0) {
+            st->obj_track = v;
+            if (a.track == 2) a.objhist[slot] = a.half_xsq + v;
+        }
     }
     return;
 sync_failed:

@@ -587,6 +587,23 @@ class RRIEngine(object):
         self._check(self._lib.rri_onchip_fallbacks(self._h, C.byref(n)))
         return int(n.value)
 
+    def sweep_until(self, n_sweeps, obj_prev, stop_scale):
+        """Up to n_sweeps sweeps of the register-resident kernel with every sweep's objective kept and the stop rule of
+        nmf.py:510 applied on the device (rri_sweep_until): the run ends after the first sweep whose objective moved by no more
+        than stop_scale (= eps_stop |o_0 - o_1|; negative: never).  Returns (sweeps run, their objectives -- NaN where the
+        kernel left none: take objective() there), or None when the handle does not take the persistent path."""
+        n_sweeps = int(n_sweeps)
+        if not self.onchip_info()[0]:
+            return None
+        hist = np.full(n_sweeps, np.nan, dtype=np.float64)
+        done = C.c_int32(0)
+        st = self._lib.rri_sweep_until(self._h, n_sweeps, float(obj_prev), float(stop_scale),
+                                       hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done))
+        if st == _capi.RRI_ERR_UNSUPPORTED:
+            return None
+        n_done = self._drive(st, done)
+        return n_done, hist[:n_done]
+
     def synchronize(self):
         self._check(self._lib.rri_synchronize(self._h))
 

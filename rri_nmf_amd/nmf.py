@@ -28,6 +28,7 @@ What runs where
 There is no CPU fallback for the loop: without the library / a GPU the call raises.
 """
 import logging
+import os
 import time
 
 import numpy as np
@@ -506,7 +507,41 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         if early_stop:
             eng.snapshot()
 
-        for iter_no in range(max_iter):
+        # Launch-bound sizes: once o_0 and o_1 are known, the sweep / objective / stop-rule loop below runs on the device in
+        # chunks (rri_sweep_until: the persistent kernel keeps every sweep's objective and applies the rule of
+        # optimization.py:284-291 itself) -- whenever nothing has to see W, T between the sweeps.  RRI_NMF_CHUNK=0: sweep by sweep.
+        chunked = (compute_obj_each_iter and not early_stop and not diagnostics and not store_gradients and draw_noise is None
+                   and not (project_W_each_iter and not fix_W and w_row_sum is not None) and group is None
+                   and os.environ.get('RRI_NMF_CHUNK', '1') != '0')
+        iter_no = 0
+        while iter_no < max_iter:
+            if chunked and len(obj_history) >= 2 and max_iter - iter_no >= 2:
+                per_sweep = max((iter_cputime[-1] - iter_cputime[0]) / (len(iter_cputime) - 1), 1e-6)
+                budget = max_time - (time.time() - wall0)
+                m = int(min(max_iter - iter_no, 512, max(budget, 0.0) / per_sweep, max(0.5 / per_sweep, 2.0)))
+                res = eng.sweep_until(m, obj_history[-1], eps_stop * abs(obj_history[0] - obj_history[1])) if m >= 2 else None
+                if res is None or res[0] < 1:
+                    chunked = False                  # not (or no longer) on the persistent path
+                else:
+                    done, hist = res
+                    c0, c1 = iter_cputime[-1], time.perf_counter()
+                    stop_now = False
+                    for j in range(done):
+                        # NaN: the sweep an event interrupted, or one that ran launch by launch -- the kernel left no value
+                        obj_history.append(float(hist[j]) if not np.isnan(hist[j]) else eng.objective())
+                        logger.info('\tObj: {0:3.3e}'.format(obj_history[-1]))
+                        iter_cputime.append(c0 + (j + 1) * (c1 - c0) / done)      # one launch: the sweeps share its time evenly
+                        iter_no += 1
+                        if universal_stopping_condition(obj_history, eps_stop=eps_stop):
+                            logger.info('STOPPING because obj_history after iter %d' % (iter_no - 1))
+                            stop_now = True
+                            break
+                    if stop_now:
+                        break
+                    if time.time() - wall0 >= max_time:
+                        logger.info('STOPPING because max_time after iter %d' % (iter_no - 1))
+                        break
+                    continue
             if early_stop:                       # nmf.py:381-407
                 if callable(early_stop):
                     entries = getattr(early_stop, 'device_entries', None)
@@ -560,6 +595,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
             if compute_obj_each_iter and universal_stopping_condition(obj_history, eps_stop=eps_stop):
                 logger.info('STOPPING because obj_history after iter %d' % iter_no)
                 break
+            iter_no += 1
 
         iter_cputime = [c - clock0 for c in iter_cputime]
 

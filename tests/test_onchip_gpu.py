@@ -490,3 +490,57 @@ def test_the_objective_the_persistent_sweep_leaves_behind(monkeypatch, flags):
         assert rel.max() < 1e-9, (name, rel)
         assert abs(got['tracked'][3] - got[name][3]) < 1e-9 * abs(got[name][3])
         assert abs(got['tracked'][3] - got['tracked'][2][-1]) < 1e-12 * abs(got['tracked'][3])      # 5 sweeps in one launch or in five
+
+@pytest.mark.parametrize('case', ['plain, the rule ends the run', 'plain, never stops', 'topic-model flags', 'regularised',
+                                  'reset events inside a chunk', 'max_iter = 3'])
+def test_nmf_runs_the_sweep_objective_stop_loop_on_the_device_in_chunks(monkeypatch, case):
+    """nmf()'s loop -- sweep, objective, stop rule (nmf.py:377-516) -- as rri_sweep_until: the persistent kernel keeps every
+    sweep's objective and ends the launch after the first sweep that satisfies optimization.py:284-291.  Against the same call
+    sweep by sweep (RRI_NMF_CHUNK=0): the same number of sweeps, the same objectives, the same bits in W and T."""
+    from rri_nmf_amd import nmf as nmf_mod
+    n, d, k = 3000, 700, 8
+    X = planted_X(n, d, k, seed=141, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=142)
+    kw = dict(max_iter=60, eps_stop=1e-3, compute_obj_each_iter=True, dtype=np.float32)
+    if case == 'plain, never stops':
+        kw.update(eps_stop=-1, max_iter=25)
+    elif case == 'topic-model flags':
+        X = X / X.sum(1, keepdims=True)
+        T0 = T0 / T0.sum(1, keepdims=True)
+        W0 = W0 / W0.sum(1, keepdims=True)
+        kw.update(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0, eps_stop=1e-2)
+    elif case == 'regularised':
+        kw.update(reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03)
+    elif case == 'reset events inside a chunk':
+        n, d, k = 600, 200, 4
+        X = planted_X(n, d, k, seed=31, dtype=np.float32)
+        W0, T0 = scaled_init(X, k, seed=32)
+        kw.update(t_row_sum=1.0, reg_w_l1=1e6, max_iter=5, eps_stop=-1)       # every W column is driven to zero: an event per topic (23 resets allowed)
+    elif case == 'max_iter = 3':
+        kw.update(max_iter=3, eps_stop=-1)
+    out = {}
+    for chunk in ('1', '0'):
+        monkeypatch.setenv('RRI_NMF_CHUNK', chunk)
+        log = '/tmp/onchip_chunk_%s.log' % chunk
+        if os.path.exists(log):
+            os.remove(log)
+        monkeypatch.setenv('RRI_ONCHIP_LOG', log)
+        np.random.seed(0)
+        with onchip(True):
+            out[chunk] = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, **kw)
+        out[chunk]['launches'] = sum(1 for _ in open(log)) if os.path.exists(log) else 0
+    a, b = out['1'], out['0']
+    print('%s: %d sweeps, %d persistent launches in chunks against %d sweep by sweep, %d resets'
+          % (case, len(a['obj_history']), a['launches'], b['launches'], a['n_resets_used']))
+    assert len(a['obj_history']) == len(b['obj_history']) == len(a['iter_cputime']) == len(b['iter_cputime'])
+    assert a['n_resets_used'] == b['n_resets_used']
+    if case == 'plain, the rule ends the run':
+        assert 4 < len(a['obj_history']) < kw['max_iter']          # the rule, not max_iter, ended it -- on the device
+    if 'reset' not in case:
+        assert a['launches'] < b['launches'] or len(a['obj_history']) <= 3
+        assert np.array_equal(a['W'], b['W']) and np.array_equal(a['T'], b['T'])
+    else:
+        assert a['n_resets_used'] >= k
+        assert relfro(a['W'], b['W']) < 1e-10 and relfro(a['T'], b['T']) < 1e-10
+    assert np.allclose(a['obj_history'], b['obj_history'], rtol=1e-11, atol=0)
+    assert np.all(np.diff(a['iter_cputime']) >= 0)

@@ -516,7 +516,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         iter_no = 0
         while iter_no < max_iter:
             if chunked and len(obj_history) >= 2 and max_iter - iter_no >= 2:
-                per_sweep = max((iter_cputime[-1] - iter_cputime[0]) / (len(iter_cputime) - 1), 1e-6)
+                per_sweep = max(iter_cputime[-1] - iter_cputime[-2], 1e-6)      # the latest sweep (the first ones carry one-off costs)
                 budget = max_time - (time.time() - wall0)
                 m = int(min(max_iter - iter_no, 512, max(budget, 0.0) / per_sweep, max(0.5 / per_sweep, 2.0)))
                 res = eng.sweep_until(m, obj_history[-1], eps_stop * abs(obj_history[0] - obj_history[1])) if m >= 2 else None

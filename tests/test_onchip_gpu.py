@@ -544,3 +544,36 @@ def test_nmf_runs_the_sweep_objective_stop_loop_on_the_device_in_chunks(monkeypa
         assert relfro(a['W'], b['W']) < 1e-10 and relfro(a['T'], b['T']) < 1e-10
     assert np.allclose(a['obj_history'], b['obj_history'], rtol=1e-11, atol=0)
     assert np.all(np.diff(a['iter_cputime']) >= 0)
+
+def test_a_chunk_whose_launch_gives_up_costs_one_sweep_launch_by_launch(monkeypatch):
+    """rri_sweep_until on a grid that cannot synchronise: the fallback has no stop rule between its sweeps, so the call ends after
+    ONE sweep run launch by launch, its objective taken the ordinary way, and nmf() goes on sweep by sweep -- same sweeps, same
+    objectives as the call that never used the device loop"""
+    from rri_nmf_amd import nmf as nmf_mod
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = 2000, 600, 6
+    X = planted_X(n, d, k, seed=151, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=152)
+    kw = dict(max_iter=12, eps_stop=-1, compute_obj_each_iter=True, dtype=np.float32)
+    monkeypatch.setenv('RRI_ONCHIP_BACKOFF_MS', '0')
+    monkeypatch.setenv('RRI_NMF_CHUNK', '0')
+    with onchip(True):
+        want = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, **kw)
+    monkeypatch.setenv('RRI_NMF_CHUNK', '1')
+    real, seen = RRIEngine.sweep_until, []
+
+    def giving_up(self, *a):
+        os.environ['RRI_ONCHIP_SPIN_LIMIT'] = '0'              # read at every launch: this chunk's grid gives up at its entry
+        try:
+            res = real(self, *a)
+        finally:
+            del os.environ['RRI_ONCHIP_SPIN_LIMIT']
+        seen.append((res if res is None else (res[0], [bool(np.isnan(v)) for v in res[1]]), self.onchip_fallbacks()))
+        return res
+    monkeypatch.setattr(RRIEngine, 'sweep_until', giving_up)
+    with onchip(True):
+        got = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, **kw)
+    assert seen[0] == ((1, [True]), 1) and seen[1][0] is None, seen      # one sweep, no objective from the kernel; then not eligible
+    assert len(got['obj_history']) == len(want['obj_history']) == 12
+    assert np.allclose(got['obj_history'], want['obj_history'], rtol=1e-11, atol=0)
+    assert relfro(got['W'], want['W']) < 1e-10 and relfro(got['T'], want['T']) < 1e-10

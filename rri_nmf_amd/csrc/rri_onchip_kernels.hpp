@@ -140,8 +140,8 @@ struct OnchipNap {
     __device__ __forceinline__ void after(int rounds, int eighths) {      // eighths: 5 (RRI_ONCHIP_NAP_EIGHTHS; 0 = no naps)
         // capped at 20 us: the waits of a step are 3-15 us; one that took milliseconds (the grid was preempted: a device shared
         // with another process) says nothing about the next, and a nap of that length would take dozens of steps to decay
-        const long long waited = wall_clock64() - t0;
-        ticks = rounds > 0 ? (int)((min(waited, 3276LL) * eighths) >> 3) : (ticks * 3) >> 2;
+        const int waited = (int)min(wall_clock64() - t0, 0x3fffffffLL);
+        ticks = rounds > 0 ? (min(waited, 3276) * eighths) >> 3 : (ticks * 3) >> 2;
     }
 };
 // (off(u, z): z is a zero the compiler cannot see through, to be added to the lane-dependent term of the offset -- otherwise the

@@ -513,8 +513,27 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         chunked = (compute_obj_each_iter and not early_stop and not diagnostics and not store_gradients and draw_noise is None
                    and not (project_W_each_iter and not fix_W and w_row_sum is not None) and group is None
                    and os.environ.get('RRI_NMF_CHUNK', '1') != '0')
+        # ... and without an objective to watch (the caller raised the logger's level, see the note at the logger) nothing happens
+        # between the sweeps at all: they go to the device in chunks on any handle, bounded by max_time alone
+        blind = (not compute_obj_each_iter and not early_stop and not diagnostics and not store_gradients and draw_noise is None
+                 and not (project_W_each_iter and not fix_W and w_row_sum is not None) and group is None
+                 and os.environ.get('RRI_NMF_CHUNK', '1') != '0')
         iter_no = 0
         while iter_no < max_iter:
+            if blind and len(iter_cputime) >= 2 and max_iter - iter_no >= 2:
+                per_sweep = max(iter_cputime[-1] - iter_cputime[-2], 1e-6)
+                budget = max_time - (time.time() - wall0)
+                m = int(min(max_iter - iter_no, max(budget, 0.0) / per_sweep, max(0.5 / per_sweep, 1.0)))
+                if m >= 2:
+                    c0 = iter_cputime[-1]
+                    done = eng.sweep(m)
+                    c1 = time.perf_counter()
+                    iter_cputime.extend(c0 + (j + 1) * (c1 - c0) / max(done, 1) for j in range(done))
+                    iter_no += done
+                    if time.time() - wall0 >= max_time:
+                        logger.info('STOPPING because max_time after iter %d' % (iter_no - 1))
+                        break
+                    continue
             if chunked and len(obj_history) >= 2 and max_iter - iter_no >= 2:
                 per_sweep = max(iter_cputime[-1] - iter_cputime[-2], 1e-6)      # the latest sweep (the first ones carry one-off costs)
                 budget = max_time - (time.time() - wall0)

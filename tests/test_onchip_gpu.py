@@ -577,3 +577,30 @@ def test_a_chunk_whose_launch_gives_up_costs_one_sweep_launch_by_launch(monkeypa
     assert len(got['obj_history']) == len(want['obj_history']) == 12
     assert np.allclose(got['obj_history'], want['obj_history'], rtol=1e-11, atol=0)
     assert relfro(got['W'], want['W']) < 1e-10 and relfro(got['T'], want['T']) < 1e-10
+
+@pytest.mark.parametrize('case', ['persistent path', 'launch per phase (k = 70)', 'weighted'])
+def test_without_an_objective_to_watch_nmf_hands_over_whole_runs(monkeypatch, case):
+    """the caller raised the logger's level (the documented way to switch the per-sweep objective off, nmf.py:366): nothing
+    happens between the sweeps, and they go to the device in chunks -- same bits as sweep by sweep, iter_cputime of full length"""
+    import logging
+    from rri_nmf_amd import nmf as nmf_mod
+    n, d, k = (2500, 600, 7) if case != 'launch per phase (k = 70)' else (1500, 500, 70)
+    X = planted_X(n, d, min(k, 20), seed=161, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=162)
+    kw = dict(max_iter=14, dtype=np.float32)
+    if case == 'weighted':
+        kw['W_mat'] = (np.random.RandomState(3).rand(n, d) < 0.3).astype(np.float32)
+    old = nmf_mod.logger.level
+    nmf_mod.logger.setLevel(logging.WARNING)
+    try:
+        out = {}
+        for chunk in ('1', '0'):
+            monkeypatch.setenv('RRI_NMF_CHUNK', chunk)
+            with onchip(True):
+                out[chunk] = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, **kw)
+    finally:
+        nmf_mod.logger.setLevel(old)
+    a, b = out['1'], out['0']
+    assert 'obj_history' not in a and 'obj_history' not in b
+    assert len(a['iter_cputime']) == len(b['iter_cputime']) == 14 and np.all(np.diff(a['iter_cputime']) >= 0)
+    assert np.array_equal(a['W'], b['W']) and np.array_equal(a['T'], b['T'])

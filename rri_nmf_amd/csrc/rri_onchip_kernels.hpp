@@ -121,9 +121,9 @@ __device__ __forceinline__ void onchip_stores_landed() { asm volatile("s_waitcnt
 // (issue / finish apart: the first rounds of two polls can be in flight together)
 constexpr unsigned ONCHIP_NONE = 0xffffffffu;
 // The steps of a sweep are alike: what a wave waited for in the step before it will wait for again, about as long.  2048 waves
-// that poll a few kilobytes for the 10 us a projected T row takes keep the memory side busy with exactly the channels the
-// workers' own exchange goes through (topic-model flags at 10000 x 1000: 22.9 -> 32.3 us per topic step), so a wave sleeps
-// through the first part of a wait it has reason to expect before its first load.  The estimate only moves on evidence, and
+// that poll a few kilobytes while the workers work keep the memory side busy with exactly the channels the workers' own exchange
+// goes through, so a wave sleeps through the first part of a wait it has reason to expect before its first load (measured: 3 %
+// of a plain topic step at 10000 x 1000, nothing with the projection stage).  The estimate only moves on evidence, and
 // never close to the expected arrival -- a wave that oversleeps delays the workgroups that wait for IT, whose waits then look
 // longer, and with naps that track the whole wait that feeds on itself (measured: 500 us per topic step):
 //   a wait that needed more than one round of loads saw the data arrive: nap 5/8 of that wait next time;

@@ -66,8 +66,9 @@ def print_report(text):
     for r in rows:
         name = subprocess.run(['c++filt', r['name']], stdout=subprocess.PIPE, text=True).stdout.strip()
         name = re.sub(r'\(.*', '', name)
-        print('%-48s vgpr %-4s agpr %-3s sgpr %-4s spill %s/%s  lds %-6s occ %s' % (
-            name[-48:], r.get('VGPRs', '?'), r.get('AGPRs', '?'), r.get('TotalSGPRs', '?'),
+        name = name.replace('void ', '').replace('rri::', '')
+        print('%-64s vgpr %-4s agpr %-3s sgpr %-4s spill %s/%s  lds %-6s occ %s' % (
+            name[-64:], r.get('VGPRs', '?'), r.get('AGPRs', '?'), r.get('TotalSGPRs', '?'),
             r.get('VGPRs Spill', '?'), r.get('SGPRs Spill', '?'), r.get('LDS Size [bytes/block]', '?'),
             r.get('Occupancy [waves/SIMD]', '?')))
 

@@ -164,6 +164,12 @@ struct rri_ctx {
         int* perm = nullptr;            // position in the canonical CSR
         SpWork* work = nullptr;
     } sp[2];
+    // dense weighted, one read-modify-write pass per topic step: the column sums a pass leaves for the next T row lack the
+    // rank-one term of the W update that follows it; k_wmcorr takes that term from the mask alone (Cpart: its partials)
+    double* Cpart = nullptr;
+    int cpart_rows = 0;         // rows allocated in Cpart
+    bool wcorr = false;         // the T-row step being enqueued subtracts T[wcorr_topic,:] .* sum_b Cpart[b]
+    int wcorr_topic = 0, wcorr_nrb = 0;
     bool resid_fresh = false;   // weighted: E was rebuilt and no half step has run since
     bool dt_pending = false;    // weighted: dtv holds a T-row change that E does not contain yet
     // explicit-residual schedule of the unweighted flavour (RRI_UNWEIGHTED_RESIDUAL): R = X - W T lives in E and takes
@@ -433,6 +439,7 @@ int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (nee
 int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
 int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted pass with a bit-packed mask: 8 (one mask word per
                          // chunk; +1.3 % at C5 over 4, 16 falls to one wave per SIMD: profiles/r02_weighted_pass_variants.log) or 4
+int g_wpass_one = 1;     // RRI_WPASS_ONE=0: the dense weighted flavour in two passes per topic step (read; read-modify-write), as rounds 1-3
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
 int g_onchip = 1;       // RRI_ONCHIP=0: never the register-resident persistent sweep (rri_onchip_kernels.hpp)
@@ -551,6 +558,26 @@ struct LaunchX {
             if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
             else wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, U, false>(c, trow, wc, a1, b1, a2, b2);
         }
+    }
+    // c = M^T (wn .* dw) as row-block partials in Cpart (k_wmcorr): the correction of the column sums a one-pass topic step
+    // leaves behind.  Geometry: ~4 workgroups per CU, row blocks of a multiple of 64 rows, at most 4096 (32 KiB of LDS).
+    static void wmcorr(rri_ctx* c, const double* wn, const double* dw) {
+        TimedScope ts(c, 2);
+        const bool bits = c->Mbits != nullptr;
+        const int npg = bits ? (int)((c->ldb + 255) / 256) : c->npanels;
+        i64 nrb = std::min<i64>(256, std::max<i64>(1, (4 * (i64)std::max(c->n_cu, 1) + npg - 1) / npg));
+        i64 rpb = std::min<i64>(4096, round_up((c->n + nrb - 1) / nrb, 64));
+        nrb = (c->n + rpb - 1) / rpb;
+        c->wcorr_nrb = (int)std::min<i64>(nrb, c->cpart_rows);     // (cpart_rows covers every n: see rri_create)
+        const int ncols = (int)std::min<i64>(bits ? c->ldb * 4 : c->ldm, c->LD);
+        if (bits)
+            hipLaunchKernelGGL((k_wmcorr<SX, true>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
+                               (const SX*)nullptr, (i64)0, (const unsigned*)c->Mbits, c->ldb, (int)c->n, (int)(c->ldb * 4), wn, dw,
+                               c->Cpart, c->LD, (int)rpb, npg, (const DevState*)c->st);
+        else
+            hipLaunchKernelGGL((k_wmcorr<SX, false>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
+                               (const SX*)c->M, c->ldm, (const unsigned*)nullptr, (i64)0, (int)c->n, ncols, wn, dw, c->Cpart,
+                               c->LD, (int)rpb, npg, (const DevState*)c->st);
     }
     // ---- sparse pattern (rri_sparse_kernels.hpp) ----------------------------------------------------
     template <bool DO_S, bool UPD2, bool WRITE, int LPS>
@@ -1171,10 +1198,9 @@ void w_refresh(rri_ctx* c) {
 
 void w_reduce(rri_ctx* c) {
     const int nb = (int)((c->LD + 31) / 32);
-    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, c->LD, c->nrb,
-                       (const double*)nullptr, 0, c->k, c->red, (const DevState*)c->st);
-    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Z2part, c->LD, c->nrb,
-                       (const double*)nullptr, 0, c->k, c->red + c->LD, (const DevState*)c->st);
+    hipLaunchKernelGGL(k_wreduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, (const double*)c->Z2part, c->LD,
+                       c->nrb, c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
+                       (const double*)(c->T + (i64)c->wcorr_topic * c->LD), c->red, (const DevState*)c->st);
 }
 
 // few row blocks of partial column sums, one device: the column verdict, both reductions and the closed form of the T row are
@@ -1188,6 +1214,13 @@ void enqueue_wT_sums(rri_ctx* c, int t, bool fused = false) {
     const double* wt_t = c->W + (i64)t * c->ldw;
     if (!c->carry_valid || c->carry_topic != t)
         DISPATCH(c, (L::template wpass<false, true, false, false>(c, nullptr, wt_t, c->zeros, c->zeros, nullptr, nullptr)));
+    // dense handles: E -- and with it these sums, carried or just taken -- lacks the rank-one term of the last W update
+    // (dw T[dw_topic,:]^T under the mask; the next pass folds it in).  Its share of the sums comes from the mask alone.
+    c->wcorr = !c->sparse && c->dw_pending;
+    if (c->wcorr) {
+        c->wcorr_topic = c->dw_topic;
+        DISPATCH(c, L::wmcorr(c, wt_t, c->dwv));
+    }
     if (fused) return;       // reduced inside k_wtrow_small
     TimedScope ts(c, 2);
     w_reduce(c);
@@ -1202,7 +1235,9 @@ void enqueue_wT_solve(rri_ctx* c, int sweep, int t, bool fused = false) {
         if (fused) {
             const int nb = nb_small;
             hipLaunchKernelGGL(k_wtrow_small, dim3(nb), dim3(128), 0, c->stream, (const double*)c->T, c->LD, (int)c->d, t,
-                               (const double*)c->Zpart, (const double*)c->Z2part, c->LD, c->nrb, (const double*)c->Gpart,
+                               (const double*)c->Zpart, (const double*)c->Z2part, c->LD, c->nrb,
+                               c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
+                               (const double*)(c->T + (i64)c->wcorr_topic * c->LD), (const double*)c->Gpart,
                                c->nwb256, c->k, c->pending_wcheck ? 1 : 0, c->pending_wcheck_topic, sweep, c->red, c->xraw,
                                c->tpart, c->tpart_idx, kparams(c), c->st);
             c->pending_wcheck = false;
@@ -1270,6 +1305,23 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
         const double* b2 = c->T + (i64)(c->dw_pending ? c->dw_topic : t) * c->LD;
         TimedScope ts(c, 3);
         DISPATCH(c, (L::template sp_blk<true, true, true>(c, 0, b1, b2, trow, c->W + (i64)t * c->ldw, a2, c->Ypart, c->Y2part, c->n)));
+    } else if (g_wpass_one) {
+        // Dense handles: ONE read-modify-write pass per topic step (rri_wrri_kernels.hpp, "one read-modify-write pass").  It folds
+        // the W-column change of the step before (still pending) and this step's T-row change into E, writes E, and takes the
+        // row products of this W update AND the column sums of the next T row; what those lack -- the term the update below
+        // leaves pending -- the next T-row step takes from the mask alone (enqueue_wT_sums).  Nothing pending (T fixed, first
+        // step after a rebuild): the pass only reads.
+        const bool pend_w = c->dw_pending;
+        const double* a2 = pend_w ? c->dwv : c->zeros;                 // k_wwcol below overwrites dwv after the pass has read it
+        const double* b2 = c->T + (i64)(pend_w ? c->dw_topic : t) * c->LD;
+        const double* wt_t = c->W + (i64)t * c->ldw;
+        const double* wnx = c->W + (i64)tn * c->ldw;
+        const bool cn = (k > 1) && !c->prm.fix_T;
+        if (!pend_w && b1 == c->zeros) {
+            if (cn) DISPATCH(c, (L::template wpass<true, true, false, false>(c, trow, wnx, c->zeros, c->zeros, nullptr, nullptr)));
+            else DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->zeros, c->zeros, nullptr, nullptr)));
+        } else if (cn) DISPATCH(c, (L::template wpass<true, true, true, true>(c, trow, wnx, wt_t, b1, a2, b2)));
+        else DISPATCH(c, (L::template wpass<true, false, true, true>(c, trow, nullptr, wt_t, b1, a2, b2)));
     } else {
         DISPATCH(c, (L::template wpass<true, false, false, false>(c, trow, nullptr, c->W + (i64)t * c->ldw, b1, nullptr, nullptr)));
     }
@@ -1286,6 +1338,9 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
         if (carry_next) DISPATCH(c, (L::template sp_blk<true, true, true>(c, 1, c->wold, c->dwv, wn, b1, trow, c->Zpart, c->Z2part, c->LD)));
         else DISPATCH(c, (L::template sp_blk<false, true, true>(c, 1, c->wold, c->dwv, wn, b1, trow, c->Zpart, c->Z2part, c->LD)));
         c->dw_pending = true;
+        c->dw_topic = t;
+    } else if (g_wpass_one) {
+        c->dw_pending = true;     // dwv x T[t,:] under the mask: folded into E by the pass of the next step
         c->dw_topic = t;
     } else if (carry_next) DISPATCH(c, (L::template wpass<false, true, true, true>(c, nullptr, wn, c->wold, b1, c->dwv, trow)));
     else DISPATCH(c, (L::template wpass<false, false, true, true>(c, nullptr, nullptr, c->wold, b1, c->dwv, trow)));
@@ -1677,6 +1732,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     g_pass_unroll = 8; g_pass_unroll_upd = 16; g_pass_nt = -1; g_pass_rs = 1; g_obj_direct = 0; g_pass_interleave = -1;
     g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_onchip_obj = 1; g_wpass_il = -1;
     g_wpass_uc = 8;
+    g_wpass_one = 1;
+    if (const char* e = getenv("RRI_WPASS_ONE")) g_wpass_one = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
@@ -1813,6 +1870,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         CR(hipMemsetAsync(c->Y2part, 0, (size_t)c->npanels * n * f8, c->stream));
         CR(hipMalloc((void**)&c->Z2part, (size_t)c->nrb * c->LD * f8));
         CR(hipMemsetAsync(c->Z2part, 0, (size_t)c->nrb * c->LD * f8, c->stream));
+        if (!c->sparse) {
+            c->cpart_rows = (int)std::max<i64>(256, (n + 4095) / 4096);
+            CR(hipMalloc((void**)&c->Cpart, (size_t)c->cpart_rows * c->LD * f8));
+            CR(hipMemsetAsync(c->Cpart, 0, (size_t)c->cpart_rows * c->LD * f8, c->stream));
+        }
         CR(hipMalloc((void**)&c->dtv, (size_t)c->LD * f8));
         CR(hipMalloc((void**)&c->dwv, (size_t)n * f8));
         CR(hipMalloc((void**)&c->wold, (size_t)n * f8));
@@ -1856,7 +1918,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->Cpart, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)

@@ -265,6 +265,124 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
     }
 }
 
+// ---- one read-modify-write pass per topic step (round 4) -------------------------------------------------------------
+// The pass of step t (k_wpass<DO_Y, DO_Z, UPD2, WRITE>) folds the two pending rank-one terms (dw_{t-1} t'_{t-1}^T and
+// w_t dt_t^T) into E, writes it, and takes BOTH the row products of the W update of topic t and the column sums
+// z = w_{t+1}^T E, nw = (w_{t+1}^2)^T M of the next T row -- column t+1 of W is untouched by step t.  What z lacks is the term
+// the W update of step t leaves pending, M .* (dw_t t'_t^T):
+//     a_j = z_j - t'_{t,j} c_j ,      c_j = sum_i M_ij w_{t+1,i} dw_{t,i}
+// c needs no residual: it is a pass over the MASK alone (bit-packed: n d / 8 bytes), k_wmcorr below.  nw does not change.
+// Per topic step (2 + 1/32 + 1/32) n d s bytes instead of (3 + 2/32) (nmf.py:687-701, 735-746 are what both compute).
+//
+// k_wmcorr: Cpart[rb][j] = sum over the rows i of block rb of M_ij u_i, u_i = wn_i dw_i.  4 waves = 4 adjacent column panels
+// x one row block (rpb rows, a multiple of 8); u goes through LDS (every lane of a wave reads the same row: broadcast).
+// Bit-packed: a lane owns ONE word column (4 columns) whatever the storage type, 8 words (64 rows) in flight; per mask bit
+// one bit-field extract, one conversion and one float64 fused multiply-add -- the kernel is bound by those (10^9 bits at
+// BASELINE config 5), not by the 125 MB it reads.  Array masks (weights that are not all 0 / 1): the geometry of k_pass.
+template <typename SX, bool MBITS>
+__global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ldm, const unsigned* __restrict__ Mb, i64 ldb,
+                                                int n, int ncols, const double* __restrict__ wn,
+                                                const double* __restrict__ dw, double* __restrict__ Cpart, i64 ldz, int rpb,
+                                                int npg, const DevState* __restrict__ st) {
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int CN = MBITS ? 4 : XV::N;            // columns per lane
+    if (st->halt) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ush = reinterpret_cast<double*>(smem);   // [rpb]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const int row0 = rb * rpb;
+    for (int i = threadIdx.x; i < rpb; i += 256) {
+        const int g = row0 + i;
+        ush[i] = g < n ? wn[g] * dw[g] : 0.0;
+    }
+    __syncthreads();
+    const int col = ((pg * 4 + wave) * 64 + lane) * CN;
+    if ((pg * 4 + wave) * 64 * CN >= ncols) return;  // wave-uniform
+    const bool ok = col < ncols;
+    double acc[CN];
+#pragma unroll
+    for (int e = 0; e < CN; ++e) acc[e] = 0.0;
+    if constexpr (MBITS) {
+        constexpr int UG = 8;                        // row groups (words) in flight per lane
+        const int ngroups = (n + 7) >> 3;
+        const int g0 = row0 >> 3, g1 = min(ngroups, (row0 + rpb) >> 3);
+        const i64 wc = col >> 2;
+        for (int g = g0; g < g1; g += UG) {
+            unsigned w[UG];
+#pragma unroll
+            for (int q = 0; q < UG; ++q) w[q] = (ok && g + q < g1) ? Mb[(i64)(g + q) * ldb + wc] : 0u;
+#pragma unroll
+            for (int q = 0; q < UG; ++q) {
+                const double* up = ush + ((g + q - g0) << 3);
+                if (g + q >= g1) break;              // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double u = up[r];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[e] = fma((double)((w[q] >> (r * 4 + e)) & 1u), u, acc[e]);
+                }
+            }
+        }
+    } else {
+        constexpr int U = 8;
+        const int row1 = min(n, row0 + rpb);
+        for (int r = row0; r < row1; r += U) {
+            V x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                x[u] = (r + u < row1 && ok) ? stream_load<true>(reinterpret_cast<const V*>(M + (i64)(r + u) * ldm + col)) : XV::zero();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + u >= row1) break;
+                double me[CN];
+                XV::unpack(x[u], me);
+                const double uv = ush[r + u - row0];
+#pragma unroll
+                for (int e = 0; e < CN; ++e) acc[e] = fma(me[e], uv, acc[e]);
+            }
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int e = 0; e < CN; ++e)
+            if (col + e < ldz) Cpart[(i64)rb * ldz + col + e] = acc[e];
+    }
+}
+
+// Both fixed-order reductions of a weighted T-row step in one launch (they were two launches of k_reduce), with the
+// correction above:  red[j] = sum_b Zpart[b][j] - tprow[j] sum_b Cpart[b][j] ,  red[ldz + j] = sum_b Z2part[b][j].
+// Cpart == NULL: no term pending.  Row-sharded runs all-reduce red afterwards: the correction is a sum over rows like z.
+__global__ __launch_bounds__(1024) void k_wreduce(const double* __restrict__ Zpart, const double* __restrict__ Z2part, i64 ldz,
+                                                  int nrb, const double* __restrict__ Cpart, int nrbc,
+                                                  const double* __restrict__ tprow, double* __restrict__ red,
+                                                  const DevState* __restrict__ st) {
+    if (st->halt) return;
+    __shared__ double sh[3][32 * 33];
+    const int tid = threadIdx.x;
+    const int c = tid & 31, g = tid >> 5;
+    const i64 j = (i64)blockIdx.x * 32 + c;
+    double a = 0.0, b = 0.0, cc = 0.0;
+    if (j < ldz) {
+        a = ordered_sum<8>(Zpart + j, ldz, g, nrb, 32);
+        b = ordered_sum<8>(Z2part + j, ldz, g, nrb, 32);
+        if (Cpart) cc = ordered_sum<8>(Cpart + j, ldz, g, nrbc, 32);
+    }
+    sh[0][g * 33 + c] = a;
+    sh[1][g * 33 + c] = b;
+    sh[2][g * 33 + c] = cc;
+    __syncthreads();
+    if (tid < 32 && j < ldz) {   // here c == tid
+        double sa = 0.0, sb = 0.0, sc = 0.0;
+        for (int q = 0; q < 32; ++q) { sa += sh[0][q * 33 + tid]; sb += sh[1][q * 33 + tid]; sc += sh[2][q * 33 + tid]; }
+        red[j] = Cpart ? fma(-tprow[j], sc, sa) : sa;
+        red[ldz + j] = sb;
+    }
+}
+
 // T row, vector-c qf_min (optimization.py:75-87), before the optional rescale.  red = [a | nw] (2 x ldz).
 // flags[b] = 1 when the block saw a negative denominator (-> "unbounded" unless s or ub is given).
 __global__ __launch_bounds__(128) void k_wtrow(const double* __restrict__ T, i64 ldt, int d, int t,
@@ -299,7 +417,9 @@ __device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int 
 // sums -- the same decision everywhere, nothing is updated when the step halts -- and leaves red = [a | nw] as k_reduce does.
 __global__ __launch_bounds__(128) void k_wtrow_small(const double* __restrict__ T, i64 ldt, int d, int t,
                                                      const double* __restrict__ Zpart, const double* __restrict__ Z2part,
-                                                     i64 ldz, int nrb, const double* __restrict__ Gpart, int nwb, int k,
+                                                     i64 ldz, int nrb, const double* __restrict__ Cpart, int nrbc,
+                                                     const double* __restrict__ tprow,
+                                                     const double* __restrict__ Gpart, int nwb, int k,
                                                      int check_prev, int tprev, int sweep, double* __restrict__ red,
                                                      double* __restrict__ xraw, double* __restrict__ tpart,
                                                      i64* __restrict__ flags, KParams p, DevState* st) {
@@ -322,7 +442,10 @@ __global__ __launch_bounds__(128) void k_wtrow_small(const double* __restrict__ 
     const i64 j = (i64)blockIdx.x * 128 + tid;
     double x = 0.0, neg = 0.0;
     if (j < ldz) {
-        const double a = ordered_sum<8>(Zpart + j, ldz, 0, nrb, 1), nw = ordered_sum<8>(Z2part + j, ldz, 0, nrb, 1);
+        double a = ordered_sum<8>(Zpart + j, ldz, 0, nrb, 1);
+        const double nw = ordered_sum<8>(Z2part + j, ldz, 0, nrb, 1);
+        // the rank-one term the last W update left pending in E (k_wmcorr): a_j = z_j - t'_j c_j
+        if (Cpart) a = fma(-tprow[j], ordered_sum<8>(Cpart + j, ldz, 0, nrbc, 1), a);
         red[j] = a;
         red[ldz + j] = nw;
         if (j < d) {

@@ -439,6 +439,10 @@ int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (nee
 int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
 int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted pass with a bit-packed mask: 8 (one mask word per
                          // chunk; +1.3 % at C5 over 4, 16 falls to one wave per SIMD: profiles/r02_weighted_pass_variants.log) or 4
+int g_wpass_ud = 4;      // RRI_WPASS_UD: rows in flight of the one-pass weighted step.  4 (DPP row sums, 138 VGPRs, 3 waves per SIMD): 1.458 ms at
+                         // BASELINE config 5 against 1.553 ms for 8 (LDS row sums, 240 VGPRs, 2 waves per SIMD) and 1.618 ms for 8 with
+                         // DPP row sums, engines made alternately in one process (profiles/r04_wpass_one_variants.log)
+int g_wmcorr_skip = 1;   // RRI_WMCORR_SKIP=0: k_wmcorr does not test the row factors for zero
 int g_wpass_one = 1;     // RRI_WPASS_ONE=0: the dense weighted flavour in two passes per topic step (read; read-modify-write), as rounds 1-3
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
 int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its own
@@ -550,6 +554,13 @@ struct LaunchX {
         // rank-one corrections, two sets of accumulators): 4 with an fp mask array, 8 with a bit-packed mask
         constexpr int U = DO_Y ? 8 : 4;
         const bool rs = DO_Y && g_pass_rs;
+        if constexpr (DO_Y && WRITE) {      // the one-pass step: RRI_WPASS_UD=4 -> 4 rows in flight, DPP row sums (fewer registers)
+            if (g_wpass_ud == 4) {
+                if (c->Mbits) wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, 4, false>(c, trow, wc, a1, b1, a2, b2);
+                else wpass_k<DO_Y, DO_Z, UPD2, WRITE, false, 4, false>(c, trow, wc, a1, b1, a2, b2);
+                return;
+            }
+        }
         if (c->Mbits) {
             if (rs) wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, 8, DO_Y>(c, trow, wc, a1, b1, a2, b2);
             else if (!DO_Y && g_wpass_uc == 8) wpass_k<DO_Y, DO_Z, UPD2, WRITE, true, 8, false>(c, trow, wc, a1, b1, a2, b2);
@@ -570,12 +581,16 @@ struct LaunchX {
         nrb = (c->n + rpb - 1) / rpb;
         c->wcorr_nrb = (int)std::min<i64>(nrb, c->cpart_rows);     // (cpart_rows covers every n: see rri_create)
         const int ncols = (int)std::min<i64>(bits ? c->ldb * 4 : c->ldm, c->LD);
-        if (bits)
-            hipLaunchKernelGGL((k_wmcorr<SX, true>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
+        if (bits && g_wmcorr_skip)
+            hipLaunchKernelGGL((k_wmcorr<SX, true, true>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
+                               (const SX*)nullptr, (i64)0, (const unsigned*)c->Mbits, c->ldb, (int)c->n, (int)(c->ldb * 4), wn, dw,
+                               c->Cpart, c->LD, (int)rpb, npg, (const DevState*)c->st);
+        else if (bits)
+            hipLaunchKernelGGL((k_wmcorr<SX, true, false>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
                                (const SX*)nullptr, (i64)0, (const unsigned*)c->Mbits, c->ldb, (int)c->n, (int)(c->ldb * 4), wn, dw,
                                c->Cpart, c->LD, (int)rpb, npg, (const DevState*)c->st);
         else
-            hipLaunchKernelGGL((k_wmcorr<SX, false>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
+            hipLaunchKernelGGL((k_wmcorr<SX, false, false>), dim3((unsigned)(npg * nrb)), dim3(256), (size_t)rpb * sizeof(double), c->stream,
                                (const SX*)c->M, c->ldm, (const unsigned*)nullptr, (i64)0, (int)c->n, ncols, wn, dw, c->Cpart,
                                c->LD, (int)rpb, npg, (const DevState*)c->st);
     }
@@ -1733,6 +1748,10 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_onchip_obj = 1; g_wpass_il = -1;
     g_wpass_uc = 8;
     g_wpass_one = 1;
+    g_wmcorr_skip = 1;
+    if (const char* e = getenv("RRI_WMCORR_SKIP")) g_wmcorr_skip = atoi(e) != 0;
+    g_wpass_ud = 4;
+    if (const char* e = getenv("RRI_WPASS_UD")) g_wpass_ud = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("RRI_WPASS_ONE")) g_wpass_one = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;

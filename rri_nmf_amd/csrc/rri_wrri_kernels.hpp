@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
 // Bit-packed: a lane owns ONE word column (4 columns) whatever the storage type, 8 words (64 rows) in flight; per mask bit
 // one bit-field extract, one conversion and one float64 fused multiply-add -- the kernel is bound by those (10^9 bits at
 // BASELINE config 5), not by the 125 MB it reads.  Array masks (weights that are not all 0 / 1): the geometry of k_pass.
-template <typename SX, bool MBITS>
+template <typename SX, bool MBITS, bool SKIP>
 __global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ldm, const unsigned* __restrict__ Mb, i64 ldb,
                                                 int n, int ncols, const double* __restrict__ wn,
                                                 const double* __restrict__ dw, double* __restrict__ Cpart, i64 ldz, int rpb,
@@ -310,10 +310,12 @@ __global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ld
         const int ngroups = (n + 7) >> 3;
         const int g0 = row0 >> 3, g1 = min(ngroups, (row0 + rpb) >> 3);
         const i64 wc = col >> 2;
+        const i64 wcc = ok ? wc : 0;                 // lanes beyond the last word column read (and drop) word column 0
         for (int g = g0; g < g1; g += UG) {
             unsigned w[UG];
+            // unconditional loads (a group beyond the block: its last group again, unused), so that all UG are in flight at once
 #pragma unroll
-            for (int q = 0; q < UG; ++q) w[q] = (ok && g + q < g1) ? Mb[(i64)(g + q) * ldb + wc] : 0u;
+            for (int q = 0; q < UG; ++q) w[q] = Mb[(i64)min(g + q, g1 - 1) * ldb + wcc];
 #pragma unroll
             for (int q = 0; q < UG; ++q) {
                 const double* up = ush + ((g + q - g0) << 3);
@@ -321,6 +323,9 @@ __global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ld
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const double u = up[r];
+                    // a row whose factor is zero (w_{t+1,i} = 0 or an unchanged entry of column t: both common, the columns are
+                    // clipped at zero) adds nothing: one compare instead of twelve instructions.  Every lane reads the same u.
+                    if (SKIP && u == 0.0) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc[e] = fma((double)((w[q] >> (r * 4 + e)) & 1u), u, acc[e]);

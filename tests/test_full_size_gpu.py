@@ -175,7 +175,12 @@ def test_weighted_dense_and_pattern_only_paths_agree_at_full_size(problem):
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     ew, et = rel(res['sparse64'][0], res['dense64'][0]), rel(res['sparse64'][1], res['dense64'][1])
     assert ew < 1e-6 and et < 1e-6, (ew, et)
-    assert np.allclose(res['sparse64'][2], res['dense64'][2], rtol=1e-10)
+    # the objectives of the two float64 handles: two sweeps amplify the order of the sums to 2e-11 / 2e-10 (round 4, the dense
+    # handle in one pass per topic step: 7052723.80306 vs ...80291, 6544590.59976 vs ...59870) while W, T stay within the bound
+    # above -- the bound follows that sensitivity, three orders below what the W bound would allow
+    print('C5 full size, float64 handles, dense vs pattern-only: W %.2e T %.2e objectives' % (ew, et),
+          [abs(a / b - 1.0) for a, b in zip(res['sparse64'][2], res['dense64'][2])])
+    assert np.allclose(res['sparse64'][2], res['dense64'][2], rtol=1e-9)
 
     # the masked reconstruction M .* (W T) on the 5e7 observed entries, on the device in chunks
     rows_of = torch.from_numpy(np.repeat(np.arange(N, dtype=np.int64), np.diff(indptr))).to(X.device)

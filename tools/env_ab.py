@@ -2,7 +2,7 @@
 """Two settings of the library's environment switches against each other INSIDE one process (the read-modify-write pass has
 per-process modes that drown an A/B of two processes): the switches are read by rri_create, so engines made alternately under
 setting A and setting B on the same resident X compare like with like.  Pass timed by HIP events.
-    python3 tools/env_ab.py residual|gram|c5 "VAR=1,VAR2=0" "VAR=0" [rounds]"""
+    python3 tools/env_ab.py residual|gram|c5 "VAR=1,VAR2=0" "VAR=0" [rounds [timer id: 0 pass, 1 W column, 2 T-row chain, 3 updating pass]]"""
 import os
 import sys
 
@@ -18,6 +18,7 @@ from rri_nmf_amd.engine import RRIEngine        # noqa: E402
 def main():
     what, sa, sb = sys.argv[1], sys.argv[2], sys.argv[3]
     rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    timer = int(sys.argv[5]) if len(sys.argv) > 5 else (0 if what == 'gram' else 3)
     n, d, k = 100000, 10000, 50
     dev = torch.device('cuda', 0)
     X = device_planted_shard(n, d, k, 0, dev)
@@ -50,7 +51,7 @@ def main():
             eng.timing_enable(True, every=4)
             eng.sweep(2)
             eng.synchronize()
-            cnt, ms = eng.timing_read(0 if what == 'gram' else 3)
+            cnt, ms = eng.timing_read(timer)
             row.append(ms / max(cnt, 1))
             eng.close()
         print('round %d: [%s] %.4f ms   [%s] %.4f ms' % (rnd, sa, row[0], sb, row[1]), flush=True)

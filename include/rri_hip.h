@@ -182,7 +182,9 @@ rri_status rri_argmax_rows(rri_ctx* ctx, int32_t* out_host);
  * RMSE_val (sklearn_interface.py:85-91,172-182).  idx = (i,j) pairs, vals = ratings.
  * On a handle with a communicator attached the call is collective: (i, j) are this rank's LOCAL rows (count may be 0),
  * the result is sqrt(sum of squared errors over all ranks / number of entries over all ranks), equal on every rank -- the
- * early-stop decision of nmf.py:381-407 is then the same everywhere. */
+ * early-stop decision of nmf.py:381-407 is then the same everywhere.  A rank whose own arguments are bad (an index out of range,
+ * a NULL list) still takes part in the collective and raises a flag in it: EVERY rank returns RRI_ERR_INVALID (the failing one
+ * names its entry, the others say "on another rank"), nobody is left waiting, and the ranks stay in step for the next call. */
 rri_status rri_masked_rmse(rri_ctx* ctx, const int64_t* ij, const double* vals, int64_t count,
                            double clip_lo, double clip_hi, double* out);
 /* device-side copy of (W,T) for the early-stop rollback of nmf.py:360-363,393-407 */
@@ -293,7 +295,10 @@ rri_status rri_onchip_info(rri_ctx* ctx, int32_t* eligible, int64_t* launches);
 /* The exchanges of that launch poll a bounded number of times.  When its workgroups cannot all run at once (a device shared
  * with another process, CUs masked away) the launch gives up, and the call does what the reference's sweep does under any
  * scheduling (nmf.py:415-476): it completes -- W and T are put back to what they were before the launch and the same steps
- * run on the launch-per-phase schedule, which the handle then keeps.  *fallbacks: how often that happened on this handle. */
+ * run on the launch-per-phase schedule, which the handle then keeps for a while: 2 s after its first fallback, twice as long after
+ * every further one up to 64 s (and every handle of the process stays off the path for RRI_ONCHIP_BACKOFF_MS, default 2000).
+ * *eligible of rri_onchip_info and RRI_ERR_UNSUPPORTED of rri_sweep_until therefore depend on the clock after a fallback.
+ * *fallbacks: how often that happened on this handle. */
 rri_status rri_onchip_fallbacks(rri_ctx* ctx, int64_t* fallbacks);
 /* The sweep / objective / stop-rule loop of nmf.py:377-516 for launch-bound sizes, in one call: up to n_sweeps sweeps of the
  * register-resident kernel with the objective of every sweep kept (true_objective, nmf.py:71-94, 488-490) and the rule of

@@ -246,7 +246,8 @@ struct rri_ctx {
     // W, T as they were before the launch, the host flags the launch-per-phase schedule would have started from
     double *Wsafe = nullptr, *Tsafe = nullptr;
     bool onchip_in_flight = false;      // the sequence just enqueued was a persistent launch (run_and_collect reads it)
-    bool onchip_off = false;            // after a fallback the handle stays on the launch-per-phase schedule
+    bool onchip_off = false;            // after a fallback the handle stays on the launch-per-phase schedule ...
+    long long onchip_off_until = 0;     // ... until this time (steady clock, ns): 2 s after the first fallback, doubling up to 64 s
     bool onchip_saved_skip = false;
     long onchip_fallbacks = 0;
 
@@ -442,6 +443,7 @@ int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted
 int g_wpass_ud = 4;      // RRI_WPASS_UD: rows in flight of the one-pass weighted step.  4 (DPP row sums, 138 VGPRs, 3 waves per SIMD): 1.458 ms at
                          // BASELINE config 5 against 1.553 ms for 8 (LDS row sums, 240 VGPRs, 2 waves per SIMD) and 1.618 ms for 8 with
                          // DPP row sums, engines made alternately in one process (profiles/r04_wpass_one_variants.log)
+int g_wpass_occ4 = 1;    // RRI_WPASS_OCC4=0: the one-pass step at the compiler's own register count (130: 3 waves per SIMD)
 int g_wmcorr_skip = 1;   // RRI_WMCORR_SKIP=0: k_wmcorr does not test the row factors for zero
 int g_wpass_one = 1;     // RRI_WPASS_ONE=0: the dense weighted flavour in two passes per topic step (read; read-modify-write), as rounds 1-3
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
@@ -537,6 +539,16 @@ struct LaunchX {
     static void wpass_k(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                         const double* a2, const double* b2) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
+        if constexpr (DO_Y && WRITE && U == 4) {
+            if (g_wpass_occ4) {     // the one-pass step, 4 rows in flight: the build for four waves per SIMD
+                hipLaunchKernelGGL((k_wpass_occ4<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS>), dim3(c->npanels * c->nrb),
+                                   dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
+                                   (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
+                                   wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
+                                   (const DevState*)c->st, (g_wpass_il == 1 || g_wpass_il < 0) ? c->nrb : 0);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS>), dim3(c->npanels * c->nrb),
                            dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
                            (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
@@ -1211,11 +1223,15 @@ void w_refresh(rri_ctx* c) {
     c->carry_valid = false;
 }
 
-void w_reduce(rri_ctx* c) {
-    const int nb = (int)((c->LD + 31) / 32);
+// take_check: the pending column verdict of the last W update rides in this launch (one device, rri_sweep's own loop)
+void w_reduce(rri_ctx* c, bool take_check = false, int sweep = 0, int pos = 0) {
+    const int nb = (int)((c->LD + 63) / 64);
+    const int chk = (take_check && c->pending_wcheck) ? 1 : 0;
     hipLaunchKernelGGL(k_wreduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, (const double*)c->Z2part, c->LD,
                        c->nrb, c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
-                       (const double*)(c->T + (i64)c->wcorr_topic * c->LD), c->red, (const DevState*)c->st);
+                       (const double*)(c->T + (i64)c->wcorr_topic * c->LD), c->red, (const double*)c->Gpart, c->nwb256, c->k, chk,
+                       c->pending_wcheck_topic, sweep, pos, kparams(c), c->st);
+    if (chk) c->pending_wcheck = false;
 }
 
 // few row blocks of partial column sums, one device: the column verdict, both reductions and the closed form of the T row are
@@ -1225,7 +1241,7 @@ bool wtrow_small(const rri_ctx* c) { return !c->comm && c->nrb <= 64; }
 // column sums (a, nw) of topic t over the current E into red[0 .. 2 LD)
 // `fused`: the caller goes straight on to enqueue_wT_solve(..., fused) -- rri_sweep does; the split stepping of
 // rri_topic_reduce_local / rri_topic_finish, where the host reads (and may rewrite) red in between, does not
-void enqueue_wT_sums(rri_ctx* c, int t, bool fused = false) {
+void enqueue_wT_sums(rri_ctx* c, int t, bool fused = false, bool take_check = false, int sweep = 0) {
     const double* wt_t = c->W + (i64)t * c->ldw;
     if (!c->carry_valid || c->carry_topic != t)
         DISPATCH(c, (L::template wpass<false, true, false, false>(c, nullptr, wt_t, c->zeros, c->zeros, nullptr, nullptr)));
@@ -1238,7 +1254,7 @@ void enqueue_wT_sums(rri_ctx* c, int t, bool fused = false) {
     }
     if (fused) return;       // reduced inside k_wtrow_small
     TimedScope ts(c, 2);
-    w_reduce(c);
+    w_reduce(c, take_check, sweep, t);
 }
 
 // T row from red (local sums, or all-reduced ones on the row-sharded path)
@@ -1281,7 +1297,7 @@ void enqueue_wT_solve(rri_ctx* c, int sweep, int t, bool fused = false) {
 
 void enqueue_wT_half(rri_ctx* c, int sweep, int t) {
     const bool fused = wtrow_small(c);
-    enqueue_wT_sums(c, t, fused);
+    enqueue_wT_sums(c, t, fused, /*take_check=*/!c->comm, sweep);
     if (c->comm) {
         // row-sharded: red = [numerator | denominator | sum of the last updated column, its negative-denominator flag]
         // is all-reduced; the pending column verdict is taken from the reduced tail (option A)
@@ -1385,7 +1401,8 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
                 if (!c->prm.fix_T && ph == 0) enqueue_wT_half(c, sa, t);
                 // the column verdict rides on the next T-row step where that step can take it: row-sharded (the all-reduce), or one
                 // device with few row blocks (k_wtrow_small)
-                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t, (c->comm != nullptr || wtrow_small(c)) && !c->prm.fix_T);
+                // (or k_wreduce: every T-row step of this loop can take it now)
+                if (!c->prm.fix_W) enqueue_wW_half(c, sa, t, !c->prm.fix_T);
             }
         }
         return;
@@ -1446,7 +1463,10 @@ long long steady_now_ns() { return (long long)std::chrono::duration_cast<std::ch
 // simplex projection of T), 2 <= k <= ONCHIP_MAX_K, on one device
 bool onchip_ok(const rri_ctx* c) {
     OnchipGeom g;
-    return g_onchip && !c->onchip_off && steady_now_ns() >= g_onchip_backoff_until.load() && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
+    // a handle that fell back tries the persistent path again once its own back-off has run out (a burst on another stream or
+    // process must not cost a long-lived handle the launch-bound speed-up for good); eligibility therefore depends on the clock
+    if (c->onchip_off && steady_now_ns() < c->onchip_off_until) return false;
+    return g_onchip && steady_now_ns() >= g_onchip_backoff_until.load() && !c->weighted && !c->explicit_resid && !c->comm && !c->sparse && c->k >= 2 &&
            c->k <= ONCHIP_MAX_K && !c->prm.fix_W && !c->prm.fix_T && c->ldx % c->VN == 0 && ((uintptr_t)c->X) % 16 == 0 &&
            onchip_geometry(c, &g);
 }
@@ -1527,6 +1547,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     a.entry_spin_limit = 40000u;        // the hand-over at kernel entry: a grid that is not resident as a whole shows within ~40 ms
     if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = a.entry_spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
     if (const char* e = getenv("RRI_ONCHIP_ENTRY_SPIN_LIMIT")) a.entry_spin_limit = (unsigned)std::max(0, atoi(e));
+    a.fail_step = -1;
+    if (const char* e = getenv("RRI_ONCHIP_FAIL_STEP")) a.fail_step = atoi(e);       // tests: give up inside the run, at this topic step of the launch
     // the last sweep of the launch runs from its topic 0: its objective can be left behind (see eacc in the kernel)
     a.track = (g_onchip_obj && (c->run_total - 1 > cur.sweep || (cur.topic == 0 && cur.phase == 0))) ? 1 : 0;
     if (c->until.active && cur.topic == 0 && cur.phase == 0 && c->run_total - cur.sweep <= ONCHIP_UNTIL_CAP && c->x_sq_valid) {
@@ -1748,6 +1770,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_onchip_obj = 1; g_wpass_il = -1;
     g_wpass_uc = 8;
     g_wpass_one = 1;
+    g_wpass_occ4 = 1;
+    if (const char* e = getenv("RRI_WPASS_OCC4")) g_wpass_occ4 = atoi(e) != 0;
     g_wmcorr_skip = 1;
     if (const char* e = getenv("RRI_WMCORR_SKIP")) g_wmcorr_skip = atoi(e) != 0;
     g_wpass_ud = 4;
@@ -1805,9 +1829,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     } else {
         // handles whose passes write a residual back (explicit-residual, dense weighted): the read-modify-write pass
         // likes ~8192 workgroups of >= 96 rows (+3 % at C3 for the residual schedule, +6 % for the weighted one)
+        // (round 4) the one-pass weighted step: ~16384 workgroups of >= 48 rows -- 1.40 against 1.50 - 1.55 ms per pass at BASELINE
+        // config 5, engines made alternately in one process; 24576: the same, 32768: 1.44; the partial column sums grow with the
+        // row blocks, +17 us per launch of the T-row chain (profiles/r04_wpass_one_variants.log)
         const bool rmw = explicit_resid || weighted == RRI_WEIGHTED_DENSE;
-        const int total_max = rmw ? 8192 : 2048;
-        const i64 rows_min = rmw ? 96 : 192;
+        const int total_max = weighted == RRI_WEIGHTED_DENSE ? 16384 : rmw ? 8192 : 2048;
+        const i64 rows_min = weighted == RRI_WEIGHTED_DENSE ? 48 : rmw ? 96 : 192;
         for (int total = total_max; total >= 512 && rpb == 0; total -= 512) {
             const int nrb_t = std::max(1, total / c->npanels);
             const i64 r = (n + nrb_t - 1) / nrb_t;
@@ -2291,6 +2318,10 @@ rri_status rri_set_params(rri_ctx* c, const rri_params* p) {
     if (p->reset_method < 0 || p->reset_method > 2) return fail(c, RRI_ERR_INVALID, "bad reset_method");
     if (p->fix_W && p->fix_T) return fail(c, RRI_ERR_INVALID, "fix_W and fix_T together leave nothing to update");
     const bool form_before = c->have_params && resid_sched(c);
+    // the objective a persistent sweep left behind has the penalties of THAT launch folded in
+    if (c->have_params && (c->prm.reg_w_l1 != p->reg_w_l1 || c->prm.reg_w_l2 != p->reg_w_l2 || c->prm.reg_t_l1 != p->reg_t_l1 ||
+                           c->prm.reg_t_l2 != p->reg_t_l2))
+        c->obj_track_valid = false;
     c->prm = *p;
     c->have_params = true;
     if (c->explicit_resid && form_before != resid_sched(c)) {
@@ -2322,12 +2353,20 @@ static rri_status run_and_collect(rri_ctx* c, Cursor from, int32_t* sweeps_done)
         c->onchip_in_flight = false;
         c->onchip_fallbacks += 1;
         c->onchip_off = true;
+        c->onchip_off_until = steady_now_ns() + (2000000000LL << std::min<long>(c->onchip_fallbacks - 1, 5));
         long long backoff_ms = 2000;                                        // the whole process: 2 s off the persistent path
         if (const char* e = getenv("RRI_ONCHIP_BACKOFF_MS")) backoff_ms = std::max(0, atoi(e));      // tests: 0
         g_onchip_backoff_until.store(steady_now_ns() + backoff_ms * 1000000LL);
         if (getenv("RRI_ONCHIP_DEBUG")) fprintf(stderr, "rri: the persistent sweep gave up; sweeps %d.. rerun launch by launch\n", from.sweep);
         HIPCHK(c, hipMemcpyAsync(c->W, c->Wsafe, (size_t)c->k * c->ldw * 8, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->T, c->Tsafe, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
+        // A launch that gave up IN the run (not at its entry) has left more than W and T behind: objective slots of the sweeps it
+        // finished (rri_sweep_until's history: "NaN = no value from the kernel" must hold for the sweeps rerun below) and
+        // DevState.obj_track.  The history goes back to "not written"; obj_track is never read for this call (onchip_in_flight is
+        // off, invalidate() drops obj_track_valid), XYpart is rewritten by the rerun's own W halves.
+        if (c->objhist && c->until.active)
+            HIPCHK(c, hipMemsetAsync(c->objhist, 0xFF, (size_t)std::min(std::max(c->until.n, 0), ONCHIP_UNTIL_CAP) * 8, c->stream));
+        c->obj_track_pending = false;
         invalidate(c);
         c->pending_wcheck = false;
         c->skip_row_finish = c->onchip_saved_skip;
@@ -2722,14 +2761,20 @@ rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, in
     // row-sharded (a communicator attached): collective; (i, j) are LOCAL rows, a rank may hold no entry at all, and the
     // score is sqrt(sum over the ranks of the squared errors / sum of the counts): the same number on every rank, so
     // the early-stop decision of nmf.py:381-407 is the same on every rank
-    if (!out || count < 0 || (count > 0 && (!ij || !vals)) || (count < 1 && !c->comm)) return fail(c, RRI_ERR_INVALID, "bad entry list");
-    for (i64 e = 0; e < count; ++e)
-        if (ij[2 * e] < 0 || ij[2 * e] >= c->n || ij[2 * e + 1] < 0 || ij[2 * e + 1] >= c->d)
-            return fail(c, RRI_ERR_INVALID, "entry %lld out of range", e);
+    // With a communicator this call is a collective: a rank that found its own arguments bad must not leave before the
+    // all-reduce its peers are about to enter (they would block inside it).  It contributes nothing, raises an error flag that
+    // travels with the sums, and EVERY rank returns the error afterwards -- the ranks stay in step.
+    const char* bad = nullptr;
+    i64 bad_entry = -1;
+    if (!out || count < 0 || (count > 0 && (!ij || !vals)) || (count < 1 && !c->comm)) bad = "bad entry list";
+    if (!bad)
+        for (i64 e = 0; e < count && !bad; ++e)
+            if (ij[2 * e] < 0 || ij[2 * e] >= c->n || ij[2 * e + 1] < 0 || ij[2 * e + 1] >= c->d) { bad = "entry out of range"; bad_entry = e; }
+    if (bad && !c->comm) return bad_entry >= 0 ? fail(c, RRI_ERR_INVALID, "entry %lld out of range", bad_entry) : fail(c, RRI_ERR_INVALID, "%s", bad);
     HIPCHK(c, hipSetDevice(c->device));
     double s = 0.0;
     hipError_t e = hipSuccess;
-    if (count > 0) {
+    if (count > 0 && !bad) {
         i64* dij = nullptr;
         double* dv = nullptr;
         e = hipMalloc((void**)&dij, (size_t)count * 2 * sizeof(i64));
@@ -2747,14 +2792,18 @@ rri_status rri_masked_rmse(rri_ctx* c, const int64_t* ij, const double* vals, in
         if (e == hipSuccess)
             for (int b = 0; b < 256; ++b) s += h[b];
     }
-    double tot[2] = {s, (double)count};
+    // [squared errors, count, ranks whose arguments were bad, ranks whose device work failed]
+    double tot[4] = {bad ? 0.0 : s, bad ? 0.0 : (double)count, bad ? 1.0 : 0.0, e != hipSuccess ? 1.0 : 0.0};
     if (c->comm) {
-        // a rank whose device work failed still takes part in the collective (its peers would wait for it otherwise) and
-        // reports its own failure afterwards
-        const rri_status r = comm_allreduce_host(c, tot, 2);
+        // a rank whose validation or device work failed still takes part in the collective (its peers would wait for it
+        // otherwise); the failure is reported on every rank afterwards
+        const rri_status r = comm_allreduce_host(c, tot, 4);
         if (r != RRI_OK) return r;
     }
+    if (bad) return bad_entry >= 0 ? fail(c, RRI_ERR_INVALID, "entry %lld out of range", bad_entry) : fail(c, RRI_ERR_INVALID, "%s", bad);
     if (e != hipSuccess) return fail(c, RRI_ERR_HIP, "masked rmse failed: %s", hipGetErrorString(e));
+    if (tot[2] > 0.0) return fail(c, RRI_ERR_INVALID, "bad entry list on another rank (%d of them)", (int)tot[2]);
+    if (tot[3] > 0.0) return fail(c, RRI_ERR_HIP, "masked rmse failed on another rank");
     if (!(tot[1] > 0.0)) return fail(c, RRI_ERR_INVALID, "no entry on any rank");
     *out = std::sqrt(tot[0] / tot[1]);
     return RRI_OK;

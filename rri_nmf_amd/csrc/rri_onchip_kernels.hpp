@@ -82,6 +82,8 @@ struct OnchipArgs {
     unsigned spin_limit;
     int nap_eighths;               // share of an observed wait slept through before the first load of the next one, in eighths
     unsigned entry_spin_limit;     // polls of the all-grid hand-over at kernel entry (short: a grid that is not resident as a whole shows here)
+    int fail_step;                 // tests (RRI_ONCHIP_FAIL_STEP): every workgroup gives up in phase B of this topic step of the launch, as if its
+                                   // polls had run out -- a launch that fails IN the run, after W, T and the objective slots have been written; -1: never
     long long* dbg;                // diagnostics build only: [2][16] accumulated 100 MHz ticks per section (workgroup 0, workgroup G-1)
     KParams p; DevState* st;
 };
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 onchip_poll_issue<4>(mkTw, toff, tv);
                 int halted = 0;
                 int failed = onchip_entry_sums<KT == 3 ? 3 : 9, 1>(mkPw, 64, k + 1, NA, tts, wave, lane, a.bar, a.spin_limit, &halted);
+                if (a.fail_step >= 0 && (int)stepq == a.fail_step) failed = 2;      // tests: the in-run give-up, at a chosen step
                 int roundsB = 0;
                 failed |= onchip_poll_finish<4>(mkTw, toff, tv, a.bar, a.spin_limit, &roundsB);
                 napB.after(roundsB, a.nap_eighths);

@@ -113,14 +113,14 @@ __global__ __launch_bounds__(256) void k_csr_pattern_bits(const i64* __restrict_
 //   e' = e - m (a1_i b1_j + [UPD2] a2_i b2_j)      (a1,a2: per row, from LDS; b1,b2: per column, registers)
 //   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , Z2part = sum_i w_i^2 m
 template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
-__global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm,
-                                               const unsigned* __restrict__ Mb, i64 ldb, int n, int ncols,
-                                               const double* __restrict__ trow, const double* __restrict__ wcol,
-                                               const double* __restrict__ a1v, const double* __restrict__ b1v,
-                                               const double* __restrict__ a2v, const double* __restrict__ b2v,
-                                               double* __restrict__ Ypart, double* __restrict__ Y2part,
-                                               double* __restrict__ Zpart, double* __restrict__ Z2part, i64 ldz,
-                                               int rpb, int npg, const DevState* __restrict__ st, int nrb_il) {
+__device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm,
+                                           const unsigned* __restrict__ Mb, i64 ldb, int n, int ncols,
+                                           const double* __restrict__ trow, const double* __restrict__ wcol,
+                                           const double* __restrict__ a1v, const double* __restrict__ b1v,
+                                           const double* __restrict__ a2v, const double* __restrict__ b2v,
+                                           double* __restrict__ Ypart, double* __restrict__ Y2part,
+                                           double* __restrict__ Zpart, double* __restrict__ Z2part, i64 ldz,
+                                           int rpb, int npg, const DevState* __restrict__ st, int nrb_il) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
@@ -153,12 +153,11 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
     __syncthreads();
     const bool ok = col < ncols;
     const bool wave_has_cols = (pg * 4 + wave) * PW < ncols;
-    double tv[VN], tsq[VN], b1[VN], b2[VN], zacc[VN], z2acc[VN];
+    double tv[VN], b1[VN], b2[VN], zacc[VN], z2acc[VN];
 #pragma unroll
     for (int e = 0; e < VN; ++e) {
         zacc[e] = z2acc[e] = 0.0;
         tv[e] = (DO_Y && ok) ? trow[col + e] : 0.0;
-        tsq[e] = tv[e] * tv[e];
         b1[e] = ok ? b1v[col + e] : 0.0;
         b2[e] = (UPD2 && ok) ? b2v[col + e] : 0.0;
     }
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
                 const double wv2 = wv * wv;
 #pragma unroll
                 for (int e = 0; e < VN; ++e) {
-                    if (DO_Y) { yp = fma(xe[e], tv[e], yp); y2p = fma(me[e], tsq[e], y2p); }
+                    if (DO_Y) { yp = fma(xe[e], tv[e], yp); y2p = fma(me[e] * tv[e], tv[e], y2p); }   // (m t) t: t^2 is not kept in registers
                     if (DO_Z) { zacc[e] = fma(wv, xe[e], zacc[e]); z2acc[e] = fma(wv2, me[e], z2acc[e]); }
                 }
                 if (DO_Y) {
@@ -264,6 +263,26 @@ __global__ __launch_bounds__(256) void k_wpass(SX* __restrict__ E, const SX* __r
         }
     }
 }
+
+#define RRI_WPASS_ARGS                                                                                                     \
+    SX *__restrict__ E, const SX *__restrict__ M, i64 ldx, i64 ldm, const unsigned *__restrict__ Mb, i64 ldb, int n, int ncols, \
+        const double *__restrict__ trow, const double *__restrict__ wcol, const double *__restrict__ a1v,                  \
+        const double *__restrict__ b1v, const double *__restrict__ a2v, const double *__restrict__ b2v,                   \
+        double *__restrict__ Ypart, double *__restrict__ Y2part, double *__restrict__ Zpart, double *__restrict__ Z2part, \
+        i64 ldz, int rpb, int npg, const DevState *__restrict__ st, int nrb_il
+#define RRI_WPASS_PASS E, M, ldx, ldm, Mb, ldb, n, ncols, trow, wcol, a1v, b1v, a2v, b2v, Ypart, Y2part, Zpart, Z2part, ldz, rpb, npg, st, nrb_il
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
+__global__ __launch_bounds__(256) void k_wpass(RRI_WPASS_ARGS) {
+    wpass_body<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT, MBITS, RS>(RRI_WPASS_PASS);
+}
+// The same pass compiled for four waves per SIMD (128 registers): the one-pass step with 4 rows in flight needs 130 as the
+// compiler allocates it freely and fits 128 without a spill when told to (8 rows in flight would spill 110).
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wpass_occ4(RRI_WPASS_ARGS) {
+    wpass_body<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT, MBITS, RS>(RRI_WPASS_PASS);
+}
+#undef RRI_WPASS_ARGS
+#undef RRI_WPASS_PASS
 
 // ---- one read-modify-write pass per topic step (round 4) -------------------------------------------------------------
 // The pass of step t (k_wpass<DO_Y, DO_Z, UPD2, WRITE>) folds the two pending rank-one terms (dw_{t-1} t'_{t-1}^T and
@@ -361,30 +380,62 @@ __global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ld
 // Both fixed-order reductions of a weighted T-row step in one launch (they were two launches of k_reduce), with the
 // correction above:  red[j] = sum_b Zpart[b][j] - tprow[j] sum_b Cpart[b][j] ,  red[ldz + j] = sum_b Z2part[b][j].
 // Cpart == NULL: no term pending.  Row-sharded runs all-reduce red afterwards: the correction is a sum over rows like z.
+// check_prev: the column verdict of the last W update (nmf.py:471-476, 793-816; k_wcheck_wcol's) is taken here, by workgroup 0,
+// at the position of THIS step -- the T-row kernel that follows returns at once when it halts the run: one launch less per step.
+__device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int sweep, int pos, const KParams& p, DevState* st);
 __global__ __launch_bounds__(1024) void k_wreduce(const double* __restrict__ Zpart, const double* __restrict__ Z2part, i64 ldz,
                                                   int nrb, const double* __restrict__ Cpart, int nrbc,
                                                   const double* __restrict__ tprow, double* __restrict__ red,
-                                                  const DevState* __restrict__ st) {
+                                                  const double* __restrict__ Gpart, int nwb, int k, int check_prev, int tprev,
+                                                  int sweep, int pos, KParams p, DevState* st) {
     if (st->halt) return;
-    __shared__ double sh[3][32 * 33];
+    __shared__ double sh[40];
     const int tid = threadIdx.x;
-    const int c = tid & 31, g = tid >> 5;
-    const i64 j = (i64)blockIdx.x * 32 + c;
-    double a = 0.0, b = 0.0, cc = 0.0;
-    if (j < ldz) {
-        a = ordered_sum<8>(Zpart + j, ldz, g, nrb, 32);
-        b = ordered_sum<8>(Z2part + j, ldz, g, nrb, 32);
-        if (Cpart) cc = ordered_sum<8>(Cpart + j, ldz, g, nrbc, 32);
+    if (check_prev && blockIdx.x == 0) {
+        double a = ordered_sum<8>(Gpart + k + 1, k + 2, tid, nwb, 1024);
+        double f = ordered_sum<8>(Gpart + k, k + 2, tid, nwb, 1024);
+        a = block_sum(a, sh);
+        f = block_sum(f, sh);
+        if (tid == 0) wcol_verdict(a, f, tprev, sweep, pos, p, st);
+        __syncthreads();
     }
-    sh[0][g * 33 + c] = a;
-    sh[1][g * 33 + c] = b;
-    sh[2][g * 33 + c] = cc;
-    __syncthreads();
-    if (tid < 32 && j < ldz) {   // here c == tid
-        double sa = 0.0, sb = 0.0, sc = 0.0;
-        for (int q = 0; q < 32; ++q) { sa += sh[0][q * 33 + tid]; sb += sh[1][q * 33 + tid]; sc += sh[2][q * 33 + tid]; }
-        red[j] = Cpart ? fma(-tprow[j], sc, sa) : sa;
-        red[ldz + j] = sb;
+    // a thread takes TWO adjacent columns (16-byte loads: 512 contiguous bytes per partial row and half-wave instead of 256 -- the
+    // partial arrays are read once, nrb x LD each, and with the small row blocks the writing passes like there are a thousand
+    // rows of them); every column is still summed over the rows in the same fixed order: g, g + 32, ... then the 32 groups
+    const int c = tid & 31, g = tid >> 5;
+    const i64 j = (i64)blockIdx.x * 64 + 2 * c;
+    double a[2] = {0.0, 0.0}, b[2] = {0.0, 0.0}, cc[2] = {0.0, 0.0};
+    auto sum2 = [&](const double* __restrict__ P, int rows, double (&out)[2]) {
+        for (int i = g; i < rows; i += 32 * 8) {
+            f64x2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ii = i + q * 32;
+                v[q] = ii < rows ? *reinterpret_cast<const f64x2*>(P + (i64)ii * ldz + j) : f64x2{0.0, 0.0};
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { out[0] += v[q][0]; out[1] += v[q][1]; }
+        }
+    };
+    if (j < ldz) {      // ldz is even and j is even: the pair is inside the row
+        sum2(Zpart, nrb, a);
+        sum2(Z2part, nrb, b);
+        if (Cpart) sum2(Cpart, nrbc, cc);
+    }
+    __shared__ double sh2[3][32 * 33];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        sh2[0][g * 33 + c] = a[h];
+        sh2[1][g * 33 + c] = b[h];
+        sh2[2][g * 33 + c] = cc[h];
+        __syncthreads();
+        if (tid < 32 && j + h < ldz) {   // here c == tid
+            double sa = 0.0, sb = 0.0, sc = 0.0;
+            for (int q = 0; q < 32; ++q) { sa += sh2[0][q * 33 + tid]; sb += sh2[1][q * 33 + tid]; sc += sh2[2][q * 33 + tid]; }
+            red[j + h] = Cpart ? fma(-tprow[j + h], sc, sa) : sa;
+            red[ldz + j + h] = sb;
+        }
     }
 }
 

@@ -257,6 +257,44 @@ def case_group_rccl_single_rank(out):
         json.dump(res, f)
 
 
+def case_group_bad_score_entry(out):
+    """rri_masked_rmse is a collective under a communicator: a rank whose OWN entry list is bad (an index out of range) must
+    still enter the all-reduce -- its peer would block in it otherwise -- and both ranks must see the failure; the next score,
+    with good lists, must work (the ranks are still in step)"""
+    import torch.distributed as dist
+    from rri_nmf_amd.distributed import RowGroup
+    from rri_nmf_amd.engine import RRIEngine
+    rank, world = _init_pg('gloo')
+    res = {}
+    try:
+        n, d, k = 400, 90, 3
+        X, M, W0, T0 = _problem(n, d, k, False, np.dtype('float64'))
+        lo, hi = (0, 240) if rank == 0 else (240, n)
+        with RowGroup.over_torch(hi - lo) as grp, RRIEngine(hi - lo, d, k, dtype=np.float64) as e:
+            e.attach_group(grp)
+            e.upload_X(X[lo:hi]), e.set_W(W0[lo:hi]), e.set_T(T0), e.set_params()
+            I = np.arange(0, hi - lo, 7)
+            J = (I * 3) % d
+            vals = X[lo:hi][I, J]
+            Ibad = I.copy()
+            if rank == 1:
+                Ibad[2] = hi - lo                  # one row beyond this rank's block
+            try:
+                e.masked_rmse(Ibad, J, vals, 0.0, 10.0)
+                res['first'] = 'no error'
+            except ValueError as ex:              # RRI_ERR_INVALID
+                res['first'] = str(ex)
+            res['second'] = e.masked_rmse(I, J, vals, 0.0, 10.0)
+            WT = W0.astype(np.float64).dot(T0.astype(np.float64))
+            Iall = np.concatenate([np.arange(0, 240, 7), 240 + np.arange(0, n - 240, 7)])
+            Jall = np.concatenate([(np.arange(0, 240, 7) * 3) % d, (np.arange(0, n - 240, 7) * 3) % d])
+            res['want'] = float(np.sqrt(np.mean((np.clip(WT[Iall, Jall], 0.0, 10.0) - X[Iall, Jall]) ** 2)))
+    finally:
+        dist.destroy_process_group()
+    with open(out, 'w') as f:
+        json.dump(res, f)
+
+
 def case_group_closed(out):
     """a closed RowGroup (and a view of it) must be refused by attach_group instead of detaching the handle"""
     from rri_nmf_amd.distributed import RowGroup

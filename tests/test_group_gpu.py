@@ -178,6 +178,17 @@ def test_recommender_estimator_fits_row_sharded_with_its_defaults(tmp_path, case
     assert float(parts[0]['score']) < 0.5 * start and float(parts[1]['score']) < 0.5 * start, (parts[0]['score'], parts[1]['score'], start)
 
 
+def test_a_bad_entry_list_on_one_rank_fails_on_both_and_leaves_them_in_step(tmp_path):
+    """rri_masked_rmse under a communicator (the held-out score of the row-sharded early stop, nmf.py:381-407): argument
+    checks used to return BEFORE the all-reduce, so a rank with one bad index left its peer blocked in the collective.  Now the
+    failing rank takes part with an error flag, both ranks report the failure, and the next call works."""
+    outs = run_children('group_bad_score_entry', 2, tmp_path)
+    res = [json.load(open(o)) for o in outs]
+    assert 'another rank' in res[0]['first'], res[0]['first']
+    assert 'out of range' in res[1]['first'], res[1]['first']
+    assert res[0]['second'] == res[1]['second'] and abs(res[0]['second'] - res[0]['want']) < 1e-12 * res[0]['want'], res
+
+
 def test_a_closed_group_is_refused_instead_of_silently_detaching(tmp_path):
     """RowGroup.close() frees the library's communicator: attaching the group -- or a view of it made by resized() -- afterwards
     must fail loudly (NULL would detach the handle: obj_calculator.true_objective() of a sharded run would quietly return one

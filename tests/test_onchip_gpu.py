@@ -272,6 +272,43 @@ def test_a_grid_that_cannot_synchronise_falls_back_to_the_launch_per_phase_sched
     assert relfro(Wc, Wb) < 1e-10 and relfro(Tc, Tb) < 1e-10
 
 
+@pytest.mark.parametrize('flags', [{}, dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)], ids=['plain', 'topic-model'])
+def test_a_launch_that_gives_up_inside_the_run_is_rolled_back_whole(monkeypatch, flags):
+    """The fallback tests above make the grid give up at its ENTRY (RRI_ONCHIP_SPIN_LIMIT=0 sets both bounds), where nothing has
+    been written yet.  Here the entry hand-over keeps its default bound and every workgroup gives up in phase B of a topic step
+    in the middle of the second sweep (RRI_ONCHIP_FAIL_STEP: as if its polls had run out there): by then the launch has rewritten
+    W columns and T rows, the cross terms of the objective and -- under rri_sweep_until -- the history slot of the first sweep.
+    The call must still return the launch-per-phase result bit for bit, with no objective of the abandoned launch left in the
+    history (rri_hip.h: NaN = the kernel left none for that sweep)."""
+    n, d, k = 3000, 800, 6
+    X = planted_X(n, d, k, seed=71, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=72)
+    Wb, Tb, ob, _ = run(X, W0, T0, 3, False, objective=True, **flags)
+    Wb1, Tb1, _, _ = run(X, W0, T0, 1, False, **flags)
+    monkeypatch.setenv('RRI_ONCHIP_BACKOFF_MS', '0')
+    monkeypatch.setenv('RRI_ONCHIP_FAIL_STEP', str(k + 2))          # third topic step of the second sweep
+    with onchip(True), engine(n, d, k, dtype=np.float32) as e:       # (i) rri_sweep
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+        assert e.onchip_info()[0] is True
+        e.sweep(3)
+        assert e.onchip_fallbacks() == 1 and e.onchip_info() == (False, 1)
+        Wa, Ta = e.get_W(), e.get_T()
+        assert np.array_equal(Wa, Wb) and np.array_equal(Ta, Tb), (relfro(Wa, Wb), relfro(Ta, Tb))
+        # the objective is evaluated for the state the rerun produced, not taken from what the abandoned launch left behind
+        assert abs(e.objective() - ob[-1]) <= 1e-12 * abs(ob[-1]), (e.objective(), ob[-1])
+    with onchip(True), engine(n, d, k, dtype=np.float32) as e:       # (ii) rri_sweep_until: the history of the call
+        e.upload_X(X), e.set_W(W0), e.set_T(T0), e.set_params(**flags)
+        o0 = e.objective()
+        res = e.sweep_until(3, o0, -1.0)
+        assert res is not None and e.onchip_fallbacks() == 1
+        n_done, hist = res
+        # the rerun has no stop rule between its sweeps: ONE sweep launch by launch, and no value of the abandoned launch --
+        # which had finished the first sweep and written its slot -- in the history
+        assert n_done == 1 and np.isnan(hist).all(), (n_done, hist)
+        assert np.array_equal(e.get_W(), Wb1) and np.array_equal(e.get_T(), Tb1)
+        assert abs(e.objective() - ob[0]) <= 1e-12 * abs(ob[0])
+
+
 def test_a_fallback_when_a_paused_run_resumes_takes_over_at_the_same_half_step(monkeypatch):
     """a run interrupted by a T-row reset resumes in the W half of that topic (cursor phase 1, the row checks of the resumed
     step skipped).  When THAT persistent launch gives up, the launch-per-phase schedule must take over at exactly that

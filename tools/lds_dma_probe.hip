@@ -31,7 +31,9 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // The pass with its rows staged through a per-wave LDS ring of S slots (1 KiB each: one row of the wave's panel), C rows per
 // chunk.  Geometry as k_pass: 4 waves = 4 adjacent panels x one row block of rpb rows (interleaved chunks when nrb_il > 0).
 // UPD = 0: row dots + column sums of X.  UPD = 2: X <- X - a b^T - a2 b2^T first, stored, products of the new X.
-template <int UPD, int S, int C, bool NT>
+// RS: the 8 row dots of a chunk are added through an LDS tile (wave_rowsum8_*: ~4 vector instructions per row) instead of six
+// DPP steps per row (30); the tile is the chunk's own ring slots, free between the reads of the chunk and their refill.
+template <int UPD, int S, int C, bool NT, bool RS = false>
 __global__ __launch_bounds__(256) void k_pass_dma(float* __restrict__ X, i64 ldx, int n, int ncols, const double* __restrict__ trow,
                                                   const double* __restrict__ wcol, double* __restrict__ Ypart,
                                                   double* __restrict__ Zpart, i64 ldz, int rpb, int npg,
@@ -98,6 +100,8 @@ __global__ __launch_bounds__(256) void k_pass_dma(float* __restrict__ X, i64 ldx
             f32x4 x[C];
 #pragma unroll
             for (int u = 0; u < C; ++u) x[u] = myring[((q % K) * C + u) * 64 + lane];
+            double* tile = reinterpret_cast<double*>(myring + ((q % K) * C) * 64);     // RS: 8 x 72 doubles of the 8 KiB just read
+            if constexpr (RS) { static_assert(!RS || C == 8, "8 rows per tile"); asm volatile("" ::: "memory"); }
 #pragma unroll
             for (int u = 0; u < C; ++u) {
                 const int rr = r + u;
@@ -116,8 +120,15 @@ __global__ __launch_bounds__(256) void k_pass_dma(float* __restrict__ X, i64 ldx
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { yp = fma(xe[e], tv[e], yp); zacc[e] = fma(wv, xe[e], zacc[e]); }
                 if (!(rr < n && ok)) yp = 0.0;
-                const double tot = wave_sum_lane63<double>(yp);
-                if (lane == 63) ysh[wave * rpb + l0 + u] = tot;
+                if constexpr (RS) wave_rowsum8_park(tile, u, lane, yp);
+                else {
+                    const double tot = wave_sum_lane63<double>(yp);
+                    if (lane == 63) ysh[wave * rpb + l0 + u] = tot;
+                }
+            }
+            if constexpr (RS) {
+                const double tot = wave_rowsum8_finish(tile, lane);
+                if ((lane & 7) == 0) ysh[wave * rpb + l0 + (lane >> 3)] = tot;
             }
             // the slots are free once the reads above have returned (their values were consumed): refill them
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -190,20 +201,21 @@ int main(int argc, char** argv) {
                 snprintf(nm, 160, "UPD %d  library k_pass (registers)      wgs %5d rpb %4d", upd, npg * nrb, rpb);
                 printf("%-64s %8.4f ms  %7.1f GB/s\n", nm, ms, bytes / ms / 1e6);
             }
-#define RUN_DMA(UPD_, S_, C_, NT_)                                                                                              \
+#define RUN_DMA(UPD_, S_, C_, NT_) RUN_DMA2(UPD_, S_, C_, NT_, false)
+#define RUN_DMA2(UPD_, S_, C_, NT_, RS_)                                                                                            \
     {                                                                                                                           \
         const size_t sh = 4 * (size_t)(S_) * 1024 + ((5 + UPD_) * (size_t)rpb) * sizeof(double);                                         \
-        CK(hipFuncSetAttribute((const void*)k_pass_dma<UPD_, S_, C_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        const double ms = timeit([&] { hipLaunchKernelGGL((k_pass_dma<UPD_, S_, C_, NT_>), dim3(npg * nrb), dim3(256), sh, 0, X, ld, n, (int)ld, trow, wcol, Yp, Zp, ld, rpb, npg, avec, bvec, avec2, bvec2, il); }, reps); \
-        snprintf(nm, 160, "UPD %d  LDS-DMA ring S %2d C %d %s LDS %3zu KB wgs %5d", UPD_, S_, C_, NT_ ? "nt" : "  ", sh / 1024, npg * nrb);            \
+        CK(hipFuncSetAttribute((const void*)k_pass_dma<UPD_, S_, C_, NT_, RS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        const double ms = timeit([&] { hipLaunchKernelGGL((k_pass_dma<UPD_, S_, C_, NT_, RS_>), dim3(npg * nrb), dim3(256), sh, 0, X, ld, n, (int)ld, trow, wcol, Yp, Zp, ld, rpb, npg, avec, bvec, avec2, bvec2, il); }, reps); \
+        snprintf(nm, 160, "UPD %d  LDS-DMA ring S %2d C %d %s %s LDS %3zu KB wgs %5d", UPD_, S_, C_, NT_ ? "nt" : "  ", RS_ ? "tile" : "dpp ", sh / 1024, npg * nrb);            \
         printf("%-64s %8.4f ms  %7.1f GB/s\n", nm, ms, bytes / ms / 1e6);                                                       \
     }
             if (geo) {
-                RUN_DMA(0, 16, 8, true) RUN_DMA(0, 12, 4, true) RUN_DMA(0, 12, 6, true) RUN_DMA(0, 8, 4, true) RUN_DMA(0, 16, 4, true) RUN_DMA(0, 20, 4, true) RUN_DMA(0, 10, 2, true)
+                RUN_DMA(0, 16, 8, true) RUN_DMA2(0, 16, 8, true, true) RUN_DMA(0, 12, 4, true) RUN_DMA(0, 8, 4, true) RUN_DMA(0, 16, 4, true)
             } else if (upd == 0) {
-                RUN_DMA(0, 8, 4, true) RUN_DMA(0, 16, 8, true) RUN_DMA(0, 16, 4, true) RUN_DMA(0, 24, 8, true) RUN_DMA(0, 32, 8, true) RUN_DMA(0, 16, 8, false)
+                RUN_DMA2(0, 16, 8, true, true) RUN_DMA2(0, 24, 8, true, true) RUN_DMA(0, 8, 4, true) RUN_DMA(0, 16, 8, true) RUN_DMA(0, 16, 4, true) RUN_DMA(0, 24, 8, true) RUN_DMA(0, 32, 8, true) RUN_DMA(0, 16, 8, false) RUN_DMA2(0, 16, 8, true, true)
             } else {
-                RUN_DMA(2, 8, 4, true) RUN_DMA(2, 16, 8, true) RUN_DMA(2, 16, 4, true) RUN_DMA(2, 24, 8, true) RUN_DMA(2, 32, 8, true) RUN_DMA(2, 16, 8, false)
+                RUN_DMA2(2, 16, 8, true, true) RUN_DMA2(2, 24, 8, true, true) RUN_DMA(2, 8, 4, true) RUN_DMA(2, 16, 8, true) RUN_DMA(2, 16, 4, true) RUN_DMA(2, 24, 8, true) RUN_DMA(2, 32, 8, true) RUN_DMA(2, 16, 8, false)
             }
             // results: the read-only form must give the library's sums (same order per lane; the row dots meet in another order
             // only across the 4 waves -- identical here); the read-modify-write forms have moved X, so only finiteness is checked

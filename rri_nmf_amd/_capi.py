@@ -79,6 +79,7 @@ PROTOTYPES = {
     'rri_rollback': (_I32, [_P]),
     'rri_X_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
     'rri_Xt_times': (_I32, [_P, C.POINTER(_D), _I32, C.POINTER(_D)]),
+    'rri_range_finder': (_I32, [_P, C.POINTER(_D), _I32, _I32, _I32, C.POINTER(_D), C.POINTER(_D)]),
     'rri_column_positive_counts': (_I32, [_P, C.POINTER(_D)]),
     'rri_scale_X': (_I32, [_P, C.POINTER(_D), _I32]),
     'rri_comm_unique_id': (_I32, [C.POINTER(C.c_uint8)]),

@@ -1437,6 +1437,14 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
 struct OnchipGeom { int CG, RG, rows_wg, rpw, NA, kS, G; size_t shmem; };
 constexpr int ONCHIP_UNTIL_CAP = 512;   // sweeps per launch of rri_sweep_until (a slot row of 256 shares each)
 constexpr int ONCHIP_MAX_RPW = 20;    // rows per wave held in registers (float4 each): 32 spills at 256 VGPRs
+// beyond ONCHIP_SMALL_K topics the k-term dots keep 8 terms per lane and the registers take fewer resident rows WITHOUT a spill
+// (round 4, compiler's resource report: plain 18 rows / 253 VGPRs, with the projection 14 rows / 249; 20 rows spilled 10 / 16 -- and
+// 68 in round 3's build: the allocation moves with every edit, the report of `python -m rri_nmf_amd.build --report` is the record)
+constexpr int ONCHIP_MAX_RPW_K64 = 18, ONCHIP_MAX_RPW_K64_PROJ = 14;
+int onchip_rpw_cap(const rri_ctx* c, bool proj) {
+    const int cap = c->k > ONCHIP_SMALL_K ? (proj ? ONCHIP_MAX_RPW_K64_PROJ : ONCHIP_MAX_RPW_K64) : ONCHIP_MAX_RPW;
+    return c->dtype == RRI_F32 ? cap : cap / 2;       // float64 X: 8 registers per row and lane
+}
 bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     const bool proj = !LK::light(c);                   // the projection stage stages the whole T row per worker: d <= 1024
     if (c->LD > (proj ? 1024 : 2048) || c->n_cu < 1) return false;
@@ -1447,7 +1455,7 @@ bool onchip_geometry(const rri_ctx* c, OnchipGeom* g) {
     g->rpw = (g->rows_wg + g->RG - 1) / g->RG;
     g->NA = (int)((c->LD + ONCHIP_CWA - 1) / ONCHIP_CWA);      // workgroups that also own a column slice of T
     g->kS = c->k | 1;                                  // odd row stride of the LDS copy of W: no bank conflicts down a column
-    if (g->rpw > (c->dtype == RRI_F32 ? ONCHIP_MAX_RPW : ONCHIP_MAX_RPW / 2) || g->NA > 64 || g->NA > g->G || (i64)g->rows_wg * g->kS > 6144) return false;
+    if (g->rpw > onchip_rpw_cap(c, proj) || g->NA > 64 || g->NA > g->G || (i64)g->rows_wg * g->kS > 6144) return false;
     const size_t doubles = (size_t)g->rows_wg * g->kS + (size_t)c->k * ONCHIP_CWA + (c->k + 2) + (c->k + 1) +
                            (size_t)ONCHIP_PG * ONCHIP_CWA + (size_t)g->CG * g->rows_wg + 2 * (size_t)g->rows_wg +
                            (size_t)ONCHIP_WAVES * 256 + (size_t)ONCHIP_WAVES * 8 * 72 + 1024 + 40;
@@ -1547,6 +1555,8 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     a.entry_spin_limit = 40000u;        // the hand-over at kernel entry: a grid that is not resident as a whole shows within ~40 ms
     if (const char* e = getenv("RRI_ONCHIP_SPIN_LIMIT")) a.spin_limit = a.entry_spin_limit = (unsigned)std::max(0, atoi(e));   // tests: 0 = give up at once
     if (const char* e = getenv("RRI_ONCHIP_ENTRY_SPIN_LIMIT")) a.entry_spin_limit = (unsigned)std::max(0, atoi(e));
+    a.jitter = 0u;
+    if (const char* e = getenv("RRI_ONCHIP_JITTER")) a.jitter = (unsigned)strtoul(e, nullptr, 10);     // tests: seeded sleeps before every exchange store and first poll
     a.fail_step = -1;
     if (const char* e = getenv("RRI_ONCHIP_FAIL_STEP")) a.fail_step = atoi(e);       // tests: give up inside the run, at this topic step of the launch
     // the last sweep of the launch runs from its topic 0: its objective can be left behind (see eacc in the kernel)
@@ -1592,10 +1602,10 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
         const bool proj = !LK::light(c);          // project_T_each_iter with a t_row_sum: the topic-model instantiation
         if (c->k > ONCHIP_SMALL_K) {              // k-term dots of 8 terms per lane (k <= 64); no diagnostics build
             if (c->dtype == RRI_F64) {
-                if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true, 8>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, true, 8>(c, g, a);
-                else e = g.rpw <= 4 ? onchip_launch<double, 4, false, false, 8>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, false, 8>(c, g, a);
-            } else if (proj) e = g.rpw <= 8 ? onchip_launch<float, 8, false, true, 8>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, true, 8>(c, g, a);
-            else e = g.rpw <= 8 ? onchip_launch<float, 8, false, false, 8>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW, false, false, 8>(c, g, a);
+                if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true, 8>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW_K64_PROJ / 2, false, true, 8>(c, g, a);
+                else e = g.rpw <= 4 ? onchip_launch<double, 4, false, false, 8>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW_K64 / 2, false, false, 8>(c, g, a);
+            } else if (proj) e = g.rpw <= 8 ? onchip_launch<float, 8, false, true, 8>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW_K64_PROJ, false, true, 8>(c, g, a);
+            else e = g.rpw <= 8 ? onchip_launch<float, 8, false, false, 8>(c, g, a) : onchip_launch<float, ONCHIP_MAX_RPW_K64, false, false, 8>(c, g, a);
         } else if (c->dtype == RRI_F64) {         // 8 registers per row and lane: half the rows of the fp32 instantiations
             if (proj) e = g.rpw <= 4 ? onchip_launch<double, 4, false, true>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2, false, true>(c, g, a);
             else e = g.rpw <= 4 ? onchip_launch<double, 4>(c, g, a) : onchip_launch<double, ONCHIP_MAX_RPW / 2>(c, g, a);
@@ -2962,6 +2972,108 @@ rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
     (void)tm_on;
     invalidate(c);   // Zpart / red were used as scratch
     return to_host(c, outm.p, c->LD, out, m, RRI_F64, c->d, m, RRI_F64, true);
+}
+
+// ---- the range finder of the randomized SVD, on the device ---------------------------------------------------------------
+// sklearn.utils.extmath.randomized_svd (what initialization.py:105 calls) is: Q <- normalise(A Q), Q <- normalise(A^T Q), n_iter
+// times; Q <- qr(A Q); B = Q^T A; small SVD of B.  All of its work is the products with X (rri_X_times / rri_Xt_times), and
+// between them the (n or d) x m panels were normalised by LAPACK on the host: 0.7 of the 1.1 s of the start at 100000 x 10000
+// (DESIGN 8).  Here the panels never leave the device: every normalisation is Cholesky-QR, twice (G = Y^T Y by k_gram, its m x m
+// Cholesky factor on the host -- 60 x 60 --, Y <- Y L^-T by k_lsolve_rows) -- another basis of the same range than LU / QR give,
+// so U, S, V of the SVD that follows are scikit-learn's up to rounding (the row-sharded start has done the same since round 2).
+namespace {
+// lower Cholesky factor of the symmetric m x m G (row-major) in place; a pivot that is not positive gets a relative ridge
+bool host_cholesky(std::vector<double>& G, int m) {
+    double tr = 0.0;
+    for (int i = 0; i < m; ++i) tr += G[(size_t)i * m + i];
+    const double ridge = 1e-13 * tr / std::max(m, 1);
+    for (int j = 0; j < m; ++j) {
+        double dj = G[(size_t)j * m + j];
+        for (int q = 0; q < j; ++q) dj -= G[(size_t)j * m + q] * G[(size_t)j * m + q];
+        if (!(dj > 0.0)) dj = ridge > 0.0 ? ridge : 1e-300;
+        if (!std::isfinite(dj)) return false;
+        const double ljj = std::sqrt(dj);
+        G[(size_t)j * m + j] = ljj;
+        for (int i = j + 1; i < m; ++i) {
+            double v = G[(size_t)i * m + j];
+            for (int q = 0; q < j; ++q) v -= G[(size_t)i * m + q] * G[(size_t)j * m + q];
+            G[(size_t)i * m + j] = v / ljj;
+        }
+        for (int i = 0; i < j; ++i) G[(size_t)i * m + j] = 0.0;
+    }
+    return true;
+}
+// the rows of At (m x len, stride ld, device) made orthonormal: Cholesky-QR, twice
+rri_status cholqr2_rows(rri_ctx* c, double* At, i64 ld, i64 len, int m, double* Gdev) {
+    std::vector<double> G((size_t)m * m);
+    for (int round = 0; round < 2; ++round) {
+        hipLaunchKernelGGL(k_gram, dim3(m, m), dim3(256), 0, c->stream, (const double*)At, ld, len, m, Gdev);
+        HIPCHK(c, hipMemcpyAsync(G.data(), Gdev, G.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!host_cholesky(G, m)) return fail(c, RRI_ERR_INVALID, "range finder: the panel holds a non-finite value");
+        HIPCHK(c, hipMemcpyAsync(Gdev, G.data(), G.size() * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_lsolve_rows, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, At, ld, len, m, (const double*)Gdev);
+    }
+    return RRI_OK;
+}
+}  // namespace
+
+rri_status rri_range_finder(rri_ctx* c, const double* Q0, int32_t m, int32_t n_iter, int32_t transpose, double* Q_out,
+                            double* B_out) {
+    CHECK_CTX(c);
+    if (c->sparse) return fail(c, RRI_ERR_UNSUPPORTED, "a pattern-only handle takes the products one by one (rri_X_times / rri_Xt_times)");
+    if (!c->have_X) return fail(c, RRI_ERR_INVALID, "X not set");
+    if (!Q0 || !Q_out || !B_out || m < 1 || m > 64 || n_iter < 0) return fail(c, RRI_ERR_INVALID, "bad operand (1 <= m <= 64)");
+    HIPCHK(c, hipSetDevice(c->device));
+    // panels, transposed as the product kernels take them: Pd (m x LD) lives on the column side of X, Pn (m x ldw) on the row side
+    DevTmp pd, pn, zm, gd;
+    HIPCHK(c, pd.alloc((size_t)m * c->LD * sizeof(double)));
+    HIPCHK(c, pn.alloc((size_t)m * c->ldw * sizeof(double)));
+    HIPCHK(c, zm.alloc((size_t)8 * c->nrb * c->LD * sizeof(double)));
+    HIPCHK(c, gd.alloc((size_t)64 * 64 * sizeof(double)));
+    double *Pd = (double*)pd.p, *Pn = (double*)pn.p;
+    HIPCHK(c, hipMemsetAsync(Pd, 0, (size_t)m * c->LD * sizeof(double), c->stream));
+    HIPCHK(c, clear_halt(c) == RRI_OK ? hipSuccess : hipErrorUnknown);
+    const int tsave = c->timing;
+    c->timing = 0;
+    auto X_times_dev = [&]() { DISPATCH(c, L::xtt_any(c, (const double*)Pd, m, Pn)); };                 // Pn = (X Pd^T)^T
+    auto Xt_times_dev = [&]() {                                                                          // Pd = (X^T Pn^T)^T
+        for (int l = 0; l < m; l += 8)
+            DISPATCH(c, L::colsums8(c, (const double*)Pn + (i64)l * c->ldw, std::min(8, m - l), (double*)zm.p, Pd + (i64)l * c->LD));
+    };
+    rri_status s;
+    // A = X (transpose == 0: Q0 is d x m) or A = X^T (Q0 is n x m), as scikit-learn transposes when n < d
+    if (!transpose) s = to_device(c, Q0, m, RRI_F64, Pd, c->LD, c->d, m, RRI_F64, true);
+    else s = to_device(c, Q0, m, RRI_F64, Pn, c->ldw, c->n, m, RRI_F64, true);
+    for (int it = 0; it < n_iter && s == RRI_OK; ++it) {
+        if (!transpose) {
+            X_times_dev();  s = cholqr2_rows(c, Pn, c->ldw, c->n, m, (double*)gd.p);
+            if (s == RRI_OK) { Xt_times_dev(); s = cholqr2_rows(c, Pd, c->LD, c->d, m, (double*)gd.p); }
+        } else {
+            Xt_times_dev(); s = cholqr2_rows(c, Pd, c->LD, c->d, m, (double*)gd.p);
+            if (s == RRI_OK) { X_times_dev(); s = cholqr2_rows(c, Pn, c->ldw, c->n, m, (double*)gd.p); }
+        }
+    }
+    if (s == RRI_OK) {
+        if (!transpose) {       // Q = orth(X Q) (n x m), B = Q^T X (m x d)
+            X_times_dev();  s = cholqr2_rows(c, Pn, c->ldw, c->n, m, (double*)gd.p);
+            if (s == RRI_OK) Xt_times_dev();
+        } else {                // Q = orth(X^T Q) (d x m), B = Q^T X^T (m x n)
+            Xt_times_dev(); s = cholqr2_rows(c, Pd, c->LD, c->d, m, (double*)gd.p);
+            if (s == RRI_OK) X_times_dev();
+        }
+    }
+    c->timing = tsave;
+    invalidate(c);   // Zpart / red were used as scratch
+    if (s != RRI_OK) return s;
+    if (!transpose) {
+        s = to_host(c, Pn, c->ldw, Q_out, m, RRI_F64, c->n, m, RRI_F64, true);
+        if (s == RRI_OK) s = to_host(c, Pd, c->LD, B_out, c->d, RRI_F64, m, c->d, RRI_F64, false);
+    } else {
+        s = to_host(c, Pd, c->LD, Q_out, m, RRI_F64, c->d, m, RRI_F64, true);
+        if (s == RRI_OK) s = to_host(c, Pn, c->ldw, B_out, c->n, RRI_F64, m, c->n, RRI_F64, false);
+    }
+    return s;
 }
 
 // ---- preprocessing of the resident X ---------------------------------------------------------------------------

@@ -1535,6 +1535,32 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, i64 
     if (threadIdx.x == 0) { G[a * k + b] = s; G[b * k + a] = s; }
 }
 
+// A (m x len, row stride ld) <- L^-1 A for a lower-triangular L (m x m, row-major, m <= 64): forward substitution down every
+// column, one thread per column, the column in registers.  With L = chol(A A^T) the rows of the result are orthonormal:
+// the Cholesky-QR step of the range finder behind the NNDSVD start (rri_range_finder; initialization.py:105).
+__global__ __launch_bounds__(256) void k_lsolve_rows(double* __restrict__ A, i64 ld, i64 len, int m, const double* __restrict__ L) {
+    __shared__ double Lsh[64 * 64];
+    for (int e = threadIdx.x; e < m * m; e += 256) Lsh[e] = L[e];
+    __syncthreads();
+    const i64 r = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= len) return;
+    double v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = i < m ? A[(i64)i * ld + r] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        if (i < m) {
+            double acc = v[i];
+#pragma unroll
+            for (int j = 0; j < i; ++j) acc = fma(-Lsh[i * m + j], v[j], acc);
+            v[i] = acc / Lsh[i * m + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+        if (i < m) A[(i64)i * ld + r] = v[i];
+}
+
 // out[t] = sum_{b < nb} part[t * stride + b], fixed order, one workgroup per t
 __global__ __launch_bounds__(256) void k_rows_sum(const double* __restrict__ part, int nb, int stride, double* __restrict__ out) {
     __shared__ double scratch[40];

@@ -82,6 +82,8 @@ struct OnchipArgs {
     unsigned spin_limit;
     int nap_eighths;               // share of an observed wait slept through before the first load of the next one, in eighths
     unsigned entry_spin_limit;     // polls of the all-grid hand-over at kernel entry (short: a grid that is not resident as a whole shows here)
+    unsigned jitter;               // tests (RRI_ONCHIP_JITTER = seed, 0 = off): every wave sleeps a seeded pseudo-random 0-5 us before each of
+                                   // its exchange stores and first polls -- another ORDER of arrivals at every hand-over, the same results
     int fail_step;                 // tests (RRI_ONCHIP_FAIL_STEP): every workgroup gives up in phase B of this topic step of the launch, as if its
                                    // polls had run out -- a launch that fails IN the run, after W, T and the objective slots have been written; -1: never
     long long* dbg;                // diagnostics build only: [2][16] accumulated 100 MHz ticks per section (workgroup 0, workgroup G-1)
@@ -115,6 +117,17 @@ __device__ __forceinline__ void st_data(double* p, double v) {
 // this wave's agent-scope stores so far have been acknowledged (what a later store -- after a workgroup barrier: of any wave
 // -- may rely on having landed first)
 __device__ __forceinline__ void onchip_stores_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Diagnostics (OnchipArgs.jitter): what a protocol of polled slots can break on is the ORDER in which stores and polls of
+// different workgroups reach the memory side, and a quiet machine shows few orders.  With a seed, a wave sleeps 0 .. 9 naps of
+// ~0.55 us -- a hash of (seed, workgroup, wave, topic step, site) -- before every exchange store, every "absent" re-mark and every
+// first poll: each hand-over then sees its arrivals in another order, step after step (tests: the same bits as undisturbed).
+__device__ __forceinline__ void onchip_jitter(unsigned seed, int b, int wave, unsigned step, unsigned site) {
+    if (seed == 0u) return;
+    unsigned h = seed ^ ((unsigned)b * 0x9E3779B1u) ^ ((unsigned)wave * 0x85EBCA77u) ^ (step * 0xC2B2AE3Du) ^ (site * 0x27D4EB2Fu);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    const int naps = (int)(h % 10u);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(20);      // 1280 cycles each
+}
 
 // Loads v[u] = base[off(u)] (0.0 where off(u) is ONCHIP_NONE) until none is absent: `base` is wave-uniform, the offsets are
 // recomputed for every round of loads rather than kept (registers), and a round that found something absent is repeated as a
@@ -433,6 +446,8 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     // loops it was hoisted from: a scratch load and a wait per row on the critical path (100-130 spilled registers in the
     // topic-model instantiation; none in the plain one, 60 with the projection).
     int zstep = 0;
+    unsigned stepq = 0;       // topic steps of this launch so far
+#define RRI_JIT(site) onchip_jitter(a.jitter, b, wave, stepq, site)
     auto carry_pre = [&](int tn, int texcl, int buf) {
         double* mkZb = a.mkZ + (size_t)buf * G * a.LD;
         double* mkGb = a.mkG + (size_t)buf * (k + 2) * G;
@@ -451,6 +466,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) zsh[(size_t)rg * LDp + col0 + c] = za[c];
         __syncthreads();
+        RRI_JIT(1u);
 #pragma unroll 1
         for (int j = tid; j < a.LD; j += NTH) {
             double zq[8];
@@ -462,6 +478,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 if (q < RG) s += zq[q];
             st_data(mkZb + (unsigned)(b * a.LD + j), s);
         }
+        RRI_JIT(2u);
 #pragma unroll 1
         for (int e = wave; e < k + 1; e += NWV) {
             if (e == texcl) continue;                              // wave-uniform
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     auto carry_post = [&](int tn, int t, int buf) {
         double* mkGb = a.mkG + (size_t)buf * (k + 2) * G;
         if (wave < 2) {                                            // wave 0: <w_tn, w_t new>, wave 1: sum of the new column t
+            RRI_JIT(3u);
             double acc = 0.0;
 #pragma unroll 1
             for (int i = lane; i < rows_here; i += 64) {
@@ -501,7 +519,6 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
     double eacc = 0.0;
     double obj_before = a.obj_prev;      // workgroup 0: the objective of the sweep before the one that has just ended
     int chk = 0, tprev = -1;
-    unsigned stepq = 0;       // topic steps of this launch so far
 
     // Entry hand-over: every workgroup reports in and waits for all others BEFORE anything is written to W, T or the partial
     // arrays.  A grid that is not resident as a whole -- two processes' persistent grids dispatched at the same moment each
@@ -563,6 +580,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         const int q = pg + z + PG * u;
                         return (col_ok && q < G) ? (unsigned)(q * a.LD + j0 + jl) : ONCHIP_NONE;
                     };
+                    RRI_JIT(7u);
                     napA.before();
                     onchip_poll_issue<16>(mkZr, zoff, zp);
                     int never = 0;
@@ -579,6 +597,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     // worker's slots of the OTHER buffers of mkT / mkP (the next step's) go back to "absent".  The stores are
                     // acknowledged (onchip_stores_landed, then a barrier) before anything of this step is stored for the
                     // others, so whoever has seen this step's values cannot find last-but-one step's in those slots.
+                    RRI_JIT(11u);
                     if (tid < CWA && j0 + tid < a.LD) st_agent(a.mkT + (size_t)(buf ^ 1) * a.LD + (unsigned)(j0 + tid), onchip_absent_value());
                     if (tid >= 64 && tid < 64 + k + 1) st_agent(a.mkP + (size_t)(buf ^ 1) * (k + 1) * 64 + (unsigned)((tid - 64) * 64 + b), onchip_absent_value());
                     RRI_STAMP(0);
@@ -612,6 +631,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         const double* src = b == 0 ? a.objE + (size_t)slot * G : a.dec + slot;
                         const int cnt = b == 0 ? G : 1;
                         auto eoff = [&](int u, int z) -> unsigned { return lane + z + 64 * u < cnt ? (unsigned)(lane + z + 64 * u) : ONCHIP_NONE; };
+                        RRI_JIT(10u);
                         onchip_poll_issue<4>(src, eoff, es);
                         const int efailed = onchip_poll_finish<4>(src, eoff, es, a.bar, a.spin_limit);
                         if (__syncthreads_or(efailed)) goto sync_failed;
@@ -633,6 +653,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             if (b == 0 && tid == 0) { st->halt = code; st->halt_topic = -1; st->halt_sweep = s; st->halt_pos = 0; }
                         }
                     }
+                    RRI_JIT(4u);
                     if (code != 0) halt_bit = 0x80000000u;     // every worker takes the same verdict from the same sums
                     else if (tid < 8 * CWA) {
                         // the closed form for the own columns: 8 lanes per column share the PG partial column sums and the
@@ -682,6 +703,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             const double* xin = a.mkX + (size_t)buf * a.LD;
                             double r[2];
                             auto xoff = [&](int u, int z) -> unsigned { return tid + z + NTH * u < a.d ? (unsigned)(tid + z + NTH * u) : ONCHIP_NONE; };
+                            RRI_JIT(8u);
                             onchip_poll_issue<2>(xin, xoff, r);
                             const int failed = onchip_poll_finish<2>(xin, xoff, r, a.bar, a.spin_limit);
                             rowsh[tid] = tid < a.d ? r[0] : -1.0e300;                    // past d: "no element" for the fixed point
@@ -691,6 +713,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                             // has stored this step's slice, so all of them are past their reads of the step before; the stores
                             // are acknowledged before this workgroup's carry of the next step (phase B), which every reader of the
                             // next step's slices has polled first
+                            RRI_JIT(12u);
                             if (tid < CWA && j0 + tid < a.LD) st_agent(a.mkX + (size_t)(buf ^ 1) * a.LD + (unsigned)(j0 + tid), onchip_absent_value());
                         }
                         RRI_STAMP(10);                         // the whole row in LDS
@@ -770,6 +793,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                         __syncthreads();
                     }
                 }
+                RRI_JIT(5u);
                 if (halt_bit == 0u) {
                     // the row of the step for everybody (columns past d: zeros), then T T[t]^T over the own slice; [k] = sum of
                     // the row.  Thread = (entry e, quarter of the 32 columns): 8 LDS reads in flight each, the four quarters of
@@ -809,6 +833,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 // every worker's are there
                 double tv[4];
                 auto toff = [&](int c, int z) -> unsigned { return col0 + z + c < a.LD ? (unsigned)(col0 + z + c) : ONCHIP_NONE; };
+                RRI_JIT(9u);
                 napB.before();
                 onchip_poll_issue<4>(mkTw, toff, tv);
                 int halted = 0;
@@ -828,6 +853,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                 // every worker has stored its row of the step, so all of them are past their reads of this step's carry: the own
                 // slots of THIS step's buffers of mkZ / mkG (read again two steps on) go back to "absent", acknowledged before
                 // the last entries of the next step's carry are stored (carry_post, after the barrier below)
+                RRI_JIT(13u);
                 for (int j = tid; j < a.LD; j += NTH) st_agent(a.mkZ + (size_t)buf * G * a.LD + (unsigned)(b * a.LD + j), onchip_absent_value());
                 if (tid < k + 2) st_agent(a.mkG + (size_t)buf * (k + 2) * G + (unsigned)(tid * G + b), onchip_absent_value());
                 RRI_STAMP(3);
@@ -926,6 +952,7 @@ __global__ __launch_bounds__(ONCHIP_THREADS) void k_onchip_sweeps(OnchipArgs a) 
                     if (t == 0) eacc = 0.0;
                     eacc += acc;
                     if (b == 0) eacc += 0.5 * p.reg_t_l2 * tts[t] + p.reg_t_l1 * tts[k];
+                    if (t == k - 1) RRI_JIT(6u);
                     if (t == k - 1 && lane == 0 && (a.track == 2 || last_step))
                         st_data(a.objE + (unsigned)((a.track == 2 ? (s - a.s0) * G : 0) + b), eacc);
                 }
@@ -985,5 +1012,6 @@ sync_failed:
 }
 
 #undef RRI_STAMP
+#undef RRI_JIT
 
 }  // namespace rri

@@ -402,6 +402,20 @@ class RRIEngine(object):
                                            out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def range_finder(self, Q0, n_iter, transpose=False):
+        """(Q, B) of the randomized range finder on the resident X, panels on the device (rri_range_finder): A = X, or X.T when
+        `transpose`; Q0 is the (columns of A, m) test matrix, Q the orthonormal (rows of A, m) basis of range(A (A^T A)^n_iter Q0),
+        B = Q^T A.  m <= 64, dense handles."""
+        Q0 = np.ascontiguousarray(Q0, dtype=np.float64)
+        rows, cols = (self.d, self.n) if transpose else (self.n, self.d)
+        if Q0.ndim != 2 or Q0.shape[0] != cols:
+            raise ValueError('test matrix must be (%d, m)' % cols)
+        m = Q0.shape[1]
+        Q, B = np.empty((rows, m)), np.empty((m, cols))
+        self._check(self._lib.rri_range_finder(self._h, Q0.ctypes.data_as(C.POINTER(C.c_double)), m, int(n_iter), int(bool(transpose)),
+                                               Q.ctypes.data_as(C.POINTER(C.c_double)), B.ctypes.data_as(C.POINTER(C.c_double))))
+        return Q, B
+
     # ---- preprocessing of the resident X (matrixops.py:124-179) ---------------------------
     def column_positive_counts(self):
         """df[j] = #{i: X[i, j] > 0}"""

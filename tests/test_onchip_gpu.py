@@ -157,7 +157,9 @@ def test_large_k_from_a_cold_start(k):
             worst_w = max(worst_w, relfro(e.get_W()[:, t], w))
             W[:, t] = w
     print('k = %d cold start, every half step from the oracle\'s state: worst T row %.2e, worst W column %.2e' % (k, worst_t, worst_w))
-    assert worst_t < 1e-12 and worst_w < 1e-12, (worst_t, worst_w)
+    # measured: T rows 3e-13 (k = 47) and 5e-13 (k = 64) -- the numerator of a T row is a difference of sums a hundred times its size
+    # (tools/large_k_control.py) --, W columns 6e-15; the oracle's BLAS may order its sums differently on another host
+    assert worst_t < 5e-12 and worst_w < 1e-12, (worst_t, worst_w)
     # (ii) W, T now hold the oracle's sweep
     Wu, Tu = np.nextafter(W0.astype(np.float64), np.inf), T0.astype(np.float64)
     orc.plain_sweeps(X64, Wu, Tu, 1)
@@ -545,6 +547,37 @@ def test_naps_change_the_timing_of_the_polls_and_nothing_else(monkeypatch, flags
         got.append((Wg, Tg))
     for Wg, Tg in got[1:]:
         assert np.array_equal(Wg, got[0][0]) and np.array_equal(Tg, got[0][1])
+
+@pytest.mark.parametrize('shape', [(5000, 1000, 20), (3000, 700, 40)], ids=['k = 20', 'k = 40'])
+@pytest.mark.parametrize('flags', [dict(), TM], ids=['plain', 'topic-model'])
+def test_another_order_of_arrivals_at_every_hand_over_gives_the_same_bits(monkeypatch, shape, flags):
+    """The exchanges of the persistent sweep carry no flags: a slot says by its content whether the value of the step has arrived,
+    and its owner re-marks it absent "where every reader is known to be past it" (rri_onchip_kernels.hpp).  What such a protocol
+    breaks on is the ORDER in which the stores, re-marks and polls of different workgroups reach the memory side -- and a quiet
+    machine shows few orders.  RRI_ONCHIP_JITTER = seed makes every wave sleep a pseudo-random 0-5 us (a hash of seed, workgroup,
+    wave, topic step and site) before each of its exchange stores, re-marks and first polls: three seeds, the objective carried
+    along, k below and beyond one round of Gram loads -- the same bits as the undisturbed run, and as each other."""
+    n, d, k = shape
+    X = planted_X(n, d, min(k, 20), seed=171, dtype=np.float32)
+    W0, T0 = scaled_init(X, k, seed=172)
+    if flags:
+        X = X / X.sum(1, keepdims=True)
+        T0 = T0 / T0.sum(1, keepdims=True)
+        W0 = W0 / W0.sum(1, keepdims=True)
+    W0, T0, _, _ = run(X, W0, T0, 2, False, **flags)         # a warm start: the first sweeps of a long chain are ill-conditioned
+    want = run(X, W0, T0, 4, True, objective=True, **flags)
+    for seed in ('1', '77', '4242'):
+        monkeypatch.setenv('RRI_ONCHIP_JITTER', seed)
+        got = run(X, W0, T0, 4, True, objective=True, **flags)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (seed, relfro(got[0], want[0]), relfro(got[1], want[1]))
+        assert np.array_equal(got[2], want[2]), (seed, got[2], want[2])
+    monkeypatch.delenv('RRI_ONCHIP_JITTER')
+    # many sweeps in ONE launch (the slots are re-marked and reused hundreds of times), disturbed: still the undisturbed bits
+    want30 = run(X, W0, T0, 30, True, **flags)
+    monkeypatch.setenv('RRI_ONCHIP_JITTER', '9')
+    got30 = run(X, W0, T0, 30, True, **flags)
+    assert np.array_equal(got30[0], want30[0]) and np.array_equal(got30[1], want30[1])
+
 
 @pytest.mark.parametrize('flags', [dict(), dict(reg_w_l1=0.01, reg_t_l1=0.02, reg_w_l2=0.05, reg_t_l2=0.03), TM],
                          ids=['plain', 'regularised', 'topic-model'])

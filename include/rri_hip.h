@@ -201,7 +201,7 @@ rri_status rri_Xt_times(rri_ctx* ctx, const double* Q, int32_t m, double* out);
 /* The whole range finder of that randomized SVD in one call, its panels resident on the device (sklearn.utils.extmath.
  * randomized_svd behind initialization.py:105: n_iter rounds of Q <- normalise(A Q), Q <- normalise(A^T Q); Q <- orth(A Q);
  * B = Q^T A), with A = X (transpose = 0; Q0: d x m) or A = X^T (transpose = 1, scikit-learn's choice when n < d; Q0: n x m).
- * Every normalisation is Cholesky-QR, twice, instead of the host's LU / QR: another basis of the same range, so the SVD built
+ * Every normalisation is (shifted) Cholesky-QR, three passes, instead of the host's LU / QR: another basis of the same range, so the SVD built
  * on Q and B (the small SVD of B stays with the caller) is scikit-learn's up to rounding.  Q0, Q_out (rows of A x m) and
  * B_out (m x columns of A) are host arrays, row-major; 1 <= m <= 64.  Dense handles only. */
 rri_status rri_range_finder(rri_ctx* ctx, const double* Q0, int32_t m, int32_t n_iter, int32_t transpose, double* Q_out,

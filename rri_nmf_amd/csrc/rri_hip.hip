@@ -2978,19 +2978,23 @@ rri_status rri_Xt_times(rri_ctx* c, const double* Q, int32_t m, double* out) {
 // sklearn.utils.extmath.randomized_svd (what initialization.py:105 calls) is: Q <- normalise(A Q), Q <- normalise(A^T Q), n_iter
 // times; Q <- qr(A Q); B = Q^T A; small SVD of B.  All of its work is the products with X (rri_X_times / rri_Xt_times), and
 // between them the (n or d) x m panels were normalised by LAPACK on the host: 0.7 of the 1.1 s of the start at 100000 x 10000
-// (DESIGN 8).  Here the panels never leave the device: every normalisation is Cholesky-QR, twice (G = Y^T Y by k_gram, its m x m
-// Cholesky factor on the host -- 60 x 60 --, Y <- Y L^-T by k_lsolve_rows) -- another basis of the same range than LU / QR give,
+// (DESIGN 8).  Here the panels never leave the device: every normalisation is Cholesky-QR (G = Y^T Y by k_gram, its m x m
+// Cholesky factor on the host -- 60 x 60 --, Y <- Y L^-T by k_lsolve_rows; shifted in its first of three passes) -- another basis of the same range than LU / QR give,
 // so U, S, V of the SVD that follows are scikit-learn's up to rounding (the row-sharded start has done the same since round 2).
 namespace {
-// lower Cholesky factor of the symmetric m x m G (row-major) in place; a pivot that is not positive gets a relative ridge
-bool host_cholesky(std::vector<double>& G, int m) {
+// Lower Cholesky factor of the symmetric m x m G + shift_rel trace(G) I (row-major) in place.  A pivot that falls below 1e-14 of
+// its diagonal entry -- a panel that is rank-deficient to working precision: a direction the rounding of G has already lost -- is
+// held at that floor, so the factor stays finite and the direction comes out as normalised noise, as a QR would leave it.
+bool host_cholesky(std::vector<double>& G, int m, double shift_rel) {
     double tr = 0.0;
     for (int i = 0; i < m; ++i) tr += G[(size_t)i * m + i];
-    const double ridge = 1e-13 * tr / std::max(m, 1);
+    std::vector<double> d0((size_t)m);
+    for (int i = 0; i < m; ++i) { d0[(size_t)i] = G[(size_t)i * m + i] + shift_rel * tr; G[(size_t)i * m + i] = d0[(size_t)i]; }
     for (int j = 0; j < m; ++j) {
         double dj = G[(size_t)j * m + j];
         for (int q = 0; q < j; ++q) dj -= G[(size_t)j * m + q] * G[(size_t)j * m + q];
-        if (!(dj > 0.0)) dj = ridge > 0.0 ? ridge : 1e-300;
+        const double floor_j = d0[(size_t)j] > 0.0 ? 1e-14 * d0[(size_t)j] : 1e-300;
+        if (!(dj > floor_j)) dj = floor_j;
         if (!std::isfinite(dj)) return false;
         const double ljj = std::sqrt(dj);
         G[(size_t)j * m + j] = ljj;
@@ -2998,19 +3002,23 @@ bool host_cholesky(std::vector<double>& G, int m) {
             double v = G[(size_t)i * m + j];
             for (int q = 0; q < j; ++q) v -= G[(size_t)i * m + q] * G[(size_t)j * m + q];
             G[(size_t)i * m + j] = v / ljj;
+            if (!std::isfinite(G[(size_t)i * m + j])) return false;
         }
         for (int i = 0; i < j; ++i) G[(size_t)i * m + j] = 0.0;
     }
     return true;
 }
-// the rows of At (m x len, stride ld, device) made orthonormal: Cholesky-QR, twice
+// The rows of At (m x len, stride ld, device) made orthonormal by shifted Cholesky-QR, three passes (Fukaya et al.: the first
+// pass factorises G + s I, s = 1e-9 trace(G), which a panel of any condition number survives and which leaves it conditioned
+// like 1e4; the next two are plain Cholesky-QR2).  A Gaussian test matrix times a matrix with one dominant direction -- rows
+// normalised to sum 1, every document close to the mean -- is conditioned like 1e8 and worse: plain Cholesky-QR2 broke there.
 rri_status cholqr2_rows(rri_ctx* c, double* At, i64 ld, i64 len, int m, double* Gdev) {
     std::vector<double> G((size_t)m * m);
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < 3; ++round) {
         hipLaunchKernelGGL(k_gram, dim3(m, m), dim3(256), 0, c->stream, (const double*)At, ld, len, m, Gdev);
         HIPCHK(c, hipMemcpyAsync(G.data(), Gdev, G.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!host_cholesky(G, m)) return fail(c, RRI_ERR_INVALID, "range finder: the panel holds a non-finite value");
+        if (!host_cholesky(G, m, round == 0 ? 1e-9 : 0.0)) return fail(c, RRI_ERR_INVALID, "range finder: the panel holds a non-finite value");
         HIPCHK(c, hipMemcpyAsync(Gdev, G.data(), G.size() * 8, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_lsolve_rows, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, At, ld, len, m, (const double*)Gdev);
     }

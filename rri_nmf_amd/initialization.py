@@ -36,7 +36,7 @@ def randomized_svd_device(engine, n_components, random_state=None, n_oversamples
     A = engine.Xt_times if transpose else engine.X_times       # Q -> A @ Q
     At = engine.X_times if transpose else engine.Xt_times      # Q -> A.T @ Q
     Q = rng.normal(size=(n if transpose else d, m))
-    if resident and m <= 64 and not getattr(engine, 'sparse', False):
+    if resident and m <= 64 and hasattr(engine, 'range_finder') and not getattr(engine, 'sparse', False):
         # the panels stay on the device and are normalised there by Cholesky-QR (rri_range_finder) instead of travelling to the
         # host for LU / QR after every product: another basis of the same range, the same U, S, V up to rounding -- and
         # 0.7 s less at 100000 x 10000 (profiles/r04_e2e_*)
@@ -63,19 +63,36 @@ def randomized_svd_device(engine, n_components, random_state=None, n_oversamples
     return U[:, :k], s[:k], Vt[:k, :]
 
 
+def _cholesky_floor(G, shift_rel=0.0):
+    """Lower Cholesky factor of G + shift_rel trace(G) I with every pivot held at 1e-14 of its diagonal entry or above: a panel
+    that is rank-deficient to working precision keeps a finite factor (host_cholesky in csrc/rri_hip.hip, same arithmetic)."""
+    m = G.shape[0]
+    L = np.array(G, dtype=np.float64)
+    d0 = np.diag(L) + shift_rel * np.trace(L)
+    L[np.arange(m), np.arange(m)] = d0
+    for j in range(m):
+        dj = L[j, j] - np.dot(L[j, :j], L[j, :j])
+        floor = 1e-14 * d0[j] if d0[j] > 0 else 1e-300
+        if not dj > floor:
+            dj = floor
+        L[j, j] = np.sqrt(dj)
+        L[j + 1:, j] = (L[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+        L[:j, j] = 0.0
+    if not np.all(np.isfinite(L)):
+        raise ValueError('range finder: the panel holds a non-finite value')
+    return L
+
+
 def _cholqr2(Y, comm_sum):
-    """Orthonormal basis of the range of a tall matrix whose rows are spread over the ranks: Cholesky-QR, twice
-    (Y^T Y is all-reduced, R = chol, Y <- Y R^-1; the second round repairs the conditioning the first one squares).
-    Returns this rank's rows of Q."""
+    """Orthonormal basis of the range of a tall matrix whose rows are spread over the ranks: shifted Cholesky-QR, three passes
+    (Y^T Y is all-reduced, L = chol, Y <- Y L^-T; the first pass factorises G + 1e-9 trace(G) I, which a panel of any condition
+    number survives -- a Gaussian test matrix times a matrix with one dominant direction is conditioned like 1e8 -- and the next
+    two repair what it leaves; rri_range_finder does the same on one device).  Returns this rank's rows of Q."""
     from scipy import linalg
-    for _ in range(2):
+    for rnd in range(3):
         G = comm_sum(Y.T @ Y)
-        G = 0.5 * (G + G.T)
-        try:
-            R = linalg.cholesky(G, lower=False, check_finite=False)
-        except linalg.LinAlgError:       # numerically rank-deficient panel: a relative ridge keeps the factor usable
-            R = linalg.cholesky(G + 1e-13 * np.trace(G) / G.shape[0] * np.eye(G.shape[0]), lower=False, check_finite=False)
-        Y = linalg.solve_triangular(R, Y.T, trans='T', lower=False, check_finite=False).T
+        L = _cholesky_floor(0.5 * (G + G.T), 1e-9 if rnd == 0 else 0.0)
+        Y = linalg.solve_triangular(L, Y.T, lower=True, check_finite=False).T
     return Y
 
 

@@ -381,3 +381,17 @@ def test_row_sharded_call_is_checked_before_any_device_work():
             nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, group=grp, **kw)
     with pytest.raises(NotImplementedError):               # the weighted flavour always keeps its masked residual (fixed halves on a
         nmf_mod.nmf(X, 3, W_in=W0, T_in=T0, W_mat=np.ones_like(X), schedule='residual')     # residual handle run since round 3)
+
+
+def test_the_nonnegativity_check_of_the_estimator_without_a_boolean_copy():
+    """NMF_TM_Estimator.fit asserts np.all(X >= 0) (sklearn_interface.py:251); the large-array form (threads, no copy) must decide alike"""
+    from rri_nmf_amd.sklearn_interface import _all_nonnegative
+    rs = np.random.RandomState(0)
+    X = rs.rand(5000, 4000).astype(np.float32)             # above the threshold of the threaded form
+    assert _all_nonnegative(X) and _all_nonnegative(X[:10]) and _all_nonnegative(np.zeros((3, 3)))
+    for bad in (-1e-30, np.nan, -np.inf):
+        Y = X.copy()
+        Y[4999, 3999] = bad
+        assert not _all_nonnegative(Y) and not _all_nonnegative(Y[4990:])
+    import scipy.sparse as sp
+    assert _all_nonnegative(sp.csr_matrix(np.eye(3))) is True

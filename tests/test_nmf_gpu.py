@@ -247,9 +247,29 @@ def test_device_products_and_device_init(shape, store):
     assert relfro(eng.X_times(B), X64 @ B) < 1e-13
     assert relfro(eng.Xt_times(Q), X64.T @ Q) < 1e-13
     assert relfro(eng.X_times(B[:, :1]), X64 @ B[:, :1]) < 1e-13       # a single vector
-    U, S, V = randomized_svd_device(eng, k, random_state=3)
     U0, S0, V0 = randomized_svd(X64, k, random_state=3)
+    # the products on the device, the panels normalised on the host by LU / QR exactly as scikit-learn does ...
+    U, S, V = randomized_svd_device(eng, k, random_state=3, resident=False)
     assert np.allclose(S, S0, rtol=1e-10) and np.abs(U - U0).max() < 1e-8 and np.abs(V - V0).max() < 1e-8
+    # ... and (the default) the whole range finder resident on the device, its panels normalised by Cholesky-QR
+    # (rri_range_finder): another basis of the same range, the same SVD to rounding
+    U, S, V = randomized_svd_device(eng, k, random_state=3)
+    print('resident range finder %r %s: S %.2e U %.2e V %.2e' % (shape, np.dtype(store).name, np.abs(S / S0 - 1).max(), np.abs(U - U0).max(), np.abs(V - V0).max()))
+    assert np.allclose(S, S0, rtol=1e-10) and np.abs(U - U0).max() < 1e-8 and np.abs(V - V0).max() < 1e-8
+    # the call itself: Q orthonormal, B = Q^T A, for A = X and A = X^T, with and without power iterations
+    for transpose in (False, True):
+        A = X64.T if transpose else X64
+        for n_iter in (0, 3):
+            Q0 = np.random.RandomState(5).randn(A.shape[1], 16)
+            Qr, Br = eng.range_finder(Q0, n_iter, transpose=transpose)
+            assert np.abs(Qr.T @ Qr - np.eye(16)).max() < 1e-12
+            assert relfro(Br, Qr.T @ A) < 1e-12
+            Y = A @ Q0
+            for _ in range(n_iter):
+                Y = A @ np.linalg.qr(A.T @ np.linalg.qr(Y)[0])[0]
+            Qh = np.linalg.qr(Y)[0]
+            # the same subspace: the projectors agree (on what the panel resolves: its smallest directions are noise at n_iter = 3)
+            assert relfro(Qr @ (Qr.T @ Y), Y) < 1e-10 and relfro(Qh @ (Qh.T @ (Qr @ Br)), Qr @ Br) < 1e-6
     # the products do not disturb a factorisation in progress
     W0, T0 = scaled_init(X64, k, seed=2)
     eng.set_W(W0), eng.set_T(T0)

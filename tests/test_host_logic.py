@@ -393,5 +393,3 @@ def test_the_nonnegativity_check_of_the_estimator_without_a_boolean_copy():
         Y = X.copy()
         Y[4999, 3999] = bad
         assert not _all_nonnegative(Y) and not _all_nonnegative(Y[4990:])
-    import scipy.sparse as sp
-    assert _all_nonnegative(sp.csr_matrix(np.eye(3))) is True

@@ -262,6 +262,8 @@ rri_status rri_comm_stats(rri_ctx* ctx, int32_t* rank, int32_t* world, int64_t* 
  * 16-byte row stride; same protocol (one all-reduce of [numerator | denominator] per topic). */
 rri_status rri_reduce_buffer(rri_ctx* ctx, void** dev_ptr, int64_t* n_elems); /* dtype = handle's */
 rri_status rri_bind_reduce_buffer(rri_ctx* ctx, void* dev_ptr, int64_t n_elems);
+/* (T must be free; W may be fixed -- the step is then the T row alone, the kept column taking its scale, nmf.py:450-452 -- and
+ * k may be 1: the reference's loop, nmf.py:417-456, has no limit there.) */
 rri_status rri_topic_reduce_local(rri_ctx* ctx, int32_t t);
 /* Host access to the first `count` doubles of the reduce buffer between rri_topic_reduce_local and
  * rri_topic_finish: what a caller needs to perturb the T-row sums -- the Gaussian mechanism of nmf.py:422-435

@@ -3167,8 +3167,7 @@ rri_status rri_topic_reduce_local(rri_ctx* c, int32_t t) {
     CHECK_CTX(c);
     rri_status r = ready(c);
     if (r != RRI_OK) return r;
-    if (c->prm.fix_W || c->prm.fix_T || c->k < 2)
-        return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping needs k >= 2 and both halves free");
+    if (c->prm.fix_T) return fail(c, RRI_ERR_UNSUPPORTED, "split stepping is the T-row step taken apart: T must be free");
     if (c->explicit_resid) return fail(c, RRI_ERR_UNSUPPORTED, "row-sharded stepping runs the Gram-form schedule only");
     if (c->comm) return fail(c, RRI_ERR_INVALID, "a communicator is attached: rri_sweep does the collectives itself");
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
@@ -3227,7 +3226,7 @@ rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
         c->pending_wcheck = false;
         if (t < 0) return RRI_OK;
         enqueue_wT_solve(c, 0, t);
-        enqueue_wW_half(c, 0, t, true);
+        if (!c->prm.fix_W) enqueue_wW_half(c, 0, t, true);      // W fixed: the T row alone (nmf.py:417-458 without :460-476)
         return RRI_OK;
     }
     if (t < 0) {  // only the pending column check, against the (all-reduced) buffer
@@ -3239,9 +3238,18 @@ rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     }
     if (t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     const int chk = c->pending_wcheck ? 1 : 0;
-    LK::trow(c, t, chk, c->pending_wcheck_topic, 0, false);
+    // W fixed: no W half follows that would finish the row checks (they ride with the Gram row of T there), and the kept
+    // column takes the row's scale (nmf.py:450-452) -- as enqueue_T_half does
+    LK::trow(c, t, chk, c->pending_wcheck_topic, 0, c->prm.fix_W != 0);
     c->pending_wcheck = false;
     c->carry_valid = false;
+    c->q_valid = false;
+    c->xy_valid = false;
+    c->obj_track_valid = false;
+    if (c->prm.fix_W) {
+        if (no_regs(c)) LK::scale_wcol(c, t);
+        return RRI_OK;
+    }
     enqueue_W_half(c, 0, t);
     return RRI_OK;
 }
@@ -3250,6 +3258,7 @@ rri_status rri_topic_finish_w(rri_ctx* c, int32_t t) {
     CHECK_CTX(c);
     if (t < 0 || t >= c->k) return fail(c, RRI_ERR_INVALID, "topic out of range");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->prm.fix_W) return RRI_OK;   // W fixed: the step has no W half (the reset has rewritten row and column, nmf.py:770-783)
     if (c->weighted) {           // after a T-row reset: E is rebuilt from the new row and column
         if (!c->resid_valid) w_refresh(c);
         enqueue_wW_half(c, 0, t, true);

@@ -35,6 +35,7 @@ class RRIEngine(object):
         self._lib = _capi.load_library()
         self.n, self.d, self.k = int(n), int(d), int(k)
         self.dtype = np.dtype(dtype)
+        self.device = int(device)
         if self.dtype not in _NP2RRI:
             raise ValueError('dtype must be float32 or float64')
         # weighted: False | True (dense W_mat) | 'sparse' (0/1 W_mat given as a CSR pattern, upload_observed_csr)
@@ -439,7 +440,12 @@ class RRIEngine(object):
         idf = None
         if tfidf is True:
             df = self.column_positive_counts()
-            idf = np.log(self.n / (df + np.spacing(1)))       # matrixops.py:169-170
+            n_docs = self.n
+            grp = getattr(self, 'group', None)
+            if grp is not None:        # row-sharded: document frequencies are sums over the ranks, the corpus is all rows
+                df = self.comm_sum(df)
+                n_docs = grp.n_global
+            idf = np.log(n_docs / (df + np.spacing(1)))       # matrixops.py:169-170
         elif tfidf is not False and tfidf is not None:
             idf = np.asarray(tfidf, dtype=np.float64).ravel()
         if idf is not None or normalize:

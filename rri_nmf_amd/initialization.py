@@ -269,7 +269,19 @@ def _initialize_nmf_sharded(X, k, init, eps, random_state, row_normalize, engine
         W[W == 0] = fill
         H[H == 0] = fill
     elif init == 'nndsvdar':
-        raise NotImplementedError("init='nndsvdar' draws one number per zero entry of the whole W: not built row-sharded")
+        # initialization.py:147-152 draws one number per zero of W in row-major order of the WHOLE matrix, then one per zero
+        # of H, from one generator.  Every rank draws the whole W sequence (the counts of zeros per rank are exchanged) and
+        # keeps the stretch that belongs to its rows: the one-handle start, cut into row blocks.
+        rng = check_random_state(random_state)
+        fill = mean()
+        zeros_w = W == 0
+        counts = np.zeros(group.world)
+        counts[group.rank] = float(zeros_w.sum())
+        counts = comm_sum(counts).astype(np.int64)
+        before, total = int(counts[:group.rank].sum()), int(counts.sum())
+        draws = rng.randn(total)
+        W[zeros_w] = np.abs(fill * draws[before:before + int(counts[group.rank])] / 100)
+        H[H == 0] = np.abs(fill * rng.randn(int((H == 0).sum())) / 100)
     return W, (normalize(H) if row_normalize else H)
 
 

@@ -9,12 +9,15 @@ additions select the device side:
     device_init  True / False: run the products of the randomized SVD behind the NNDSVD initialisations on the
             device (initialization.randomized_svd_device) or in scikit-learn on the host; None = on the device from
             2e7 entries of X on.  Same algorithm either way.
-    group   row-sharded run over the GPUs of one node (distributed.RowGroup): X, W_in (and W_mat) are
+    group   row-sharded run over the GPUs of one node (distributed.RowGroup): X, W_in (and W_mat, w_row) are
             THIS rank's row block, T_in is the replicated k x d factor; every rank makes the same call and gets its
             rows of W, the common T and the global objective history.  Without W_in / T_in the start is computed
-            row-sharded too (initialization.randomized_svd_sharded: the one-handle start, cut into row blocks;
-            unweighted, n_global >= d).  The reference has one call for the whole X (nmf.py:98-108); this is that
-            call, made once per rank.
+            row-sharded too (initialization.randomized_svd_sharded: the one-handle start, cut into row blocks --
+            every init incl. 'nndsvdar', and the weighted start on W_mat .* X for dense inputs; n_global >= d).
+            `preprocess` (tf-idf with the document frequencies summed over the ranks, row normalisation) and `w_row`
+            (with its refit) run sharded; store_gradients, the Gaussian mechanism and host callbacks stay
+            single-handle options.  The reference has one call for the whole X (nmf.py:98-108); this is that call,
+            made once per rank.
     schedule  'gram' (default): the residual is never formed, X is read once per topic step; 'residual': the explicit
             residual R = X - W T is kept in HBM and updated by rank-one terms (the form north_star names; unweighted,
             both halves free, k >= 2).  Same results to rounding.
@@ -262,9 +265,19 @@ def _initialize_and_validate(W_in, T_in, W_mat, X, k, init, random_state, projec
             src = scipy.sparse.csr_matrix(W_mat).multiply(X).tocsr()
         else:
             src = W_mat * X
-        W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False,
-                              # the device products see X (dense handles) or X on the pattern = W_mat .* X
-                              engine=engine if (W_mat is None or getattr(engine, 'sparse', False)) else None)
+        grp = getattr(engine, 'group', None)
+        if grp is not None and W_mat is not None and not getattr(engine, 'sparse', False) and init != 'random':
+            # row-sharded weighted start (nmf.py:841-843 factorises W_mat .* X): the weighted handle keeps X and the weights
+            # apart, so the rows of W_mat .* X go up once more, onto a scratch handle under the same group, for the
+            # products of the sharded randomized SVD (initialization.randomized_svd_sharded)
+            with RRIEngine(n, d, k, dtype=engine.dtype, device=engine.device) as scratch:
+                scratch.upload_X(np.ascontiguousarray(src, dtype=engine.dtype))
+                scratch.attach_group(grp)
+                W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False, engine=scratch)
+        else:
+            W, T = initialize_nmf(src, k, init, random_state=random_state, row_normalize=False,
+                                  # the device products see X (dense handles) or X on the pattern = W_mat .* X
+                                  engine=engine if (W_mat is None or getattr(engine, 'sparse', False) or grp is not None) else None)
         if t_row_sum is not None:
             T = normalize(T) * t_row_sum
         if w_row_sum is not None:
@@ -373,25 +386,26 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     (matrixops.py:124-179) before the factorisation -- {'tfidf': True | idf vector | False, 'normalize': bool} or
     the step names.  A dense X without weights or host callbacks is uploaded raw and rewritten in place on the
     device; every other case preprocesses on the host.  The idf used comes back as rtv['idf']."""
-    if store_gradients and not fix_T and (fix_W or k < 2):
-        raise NotImplementedError('store_gradients needs both halves free and k >= 2 on the device path')
     if group is not None:
         # host work that would need the other ranks' rows (the SVD behind the NNDSVD start, document frequencies,
         # per-row weights with their refit) or that decides per rank (callbacks) is not part of the sharded call
-        if (_is_empty(W_in) or _is_empty(T_in)) and W_mat is not None:
-            raise ValueError('a row-sharded weighted call needs W_in (this rank\'s rows) and T_in')
+        if (_is_empty(W_in) or _is_empty(T_in)) and W_mat is not None and init != 'random' \
+                and (scipy.sparse.issparse(W_mat) or scipy.sparse.issparse(X)):
+            raise ValueError('a row-sharded weighted call on scipy sparse inputs needs W_in (this rank\'s rows) and T_in')
         # an early_stop callback that carries `device_entries` (what NMF_RS_Estimator.fit installs: the clipped RMSE on its
         # held-out entries, sklearn_interface.py:71-93) is scored by the library over ALL ranks' entries, so every rank takes
         # the same decision (nmf.py:381-407); a callback that wants W, T on the host would see one rank's rows
         host_stop = callable(early_stop) and getattr(early_stop, 'device_entries', None) is None
-        if w_row is not None or preprocess is not None or store_gradients or (eps_gauss_t and delta_gauss_t) or host_stop:
-            raise NotImplementedError('w_row, preprocess, store_gradients, the Gaussian mechanism and early_stop callbacks '
+        # (round 4: per-row weights -- row-local, their refit a fold-in under the same group -- and the device-side tf-idf /
+        # normalisation -- document frequencies all-reduced -- run sharded)
+        if store_gradients or (eps_gauss_t and delta_gauss_t) or host_stop:
+            raise NotImplementedError('store_gradients, the Gaussian mechanism and early_stop callbacks '
                                       'that need W, T on the host are single-handle options')
+        if preprocess is not None and (scipy.sparse.issparse(X) or W_mat is not None or w_row is not None or diagnostics):
+            raise NotImplementedError('row-sharded preprocessing runs on the device: a dense X without weights or callbacks')
     draw_noise = None
     if eps_gauss_t and delta_gauss_t and not fix_T:
         # Gaussian mechanism on the T-row sums (nmf.py:422-435; Dwork & Roth p. 261)
-        if fix_W or k < 2:
-            raise NotImplementedError('the Gaussian mechanism needs both halves free and k >= 2 on the device path')
         from scipy.stats import norm as gaussian
         c2 = 2 * np.log(1.25 / float(delta_gauss_t)) + 0.001
         df2 = 1000.0
@@ -630,7 +644,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     if w_row is not None:                        # nmf.py:531-539: refit W on the unweighted rows
         sub = nmf(X_orig, k, T_in=T, fix_T=True, max_iter=10, w_row_sum=w_row_sum,
                   project_W_each_iter=True, compute_obj_each_iter=compute_obj_each_iter,
-                  dtype=dtype, device=device)
+                  dtype=dtype, device=device, group=group)
         obj_history.extend(sub.get('obj_history', []))
         iter_cputime.extend(sub['iter_cputime'])
         W = sub['W']

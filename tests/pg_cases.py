@@ -66,6 +66,15 @@ GROUP_CASES = {
     'start_nndsvda_f32': (2000, 333, 8, 2, False, 'float32', dict(_init='nndsvda')),
     'start_smart_random': (900, 333, 5, 2, False, 'float64', dict(_init='smart_random')),
     'start_nndsvd_fold_in': (1000, 400, 5, 4, False, 'float64', dict(_init='nndsvd', _T_in=True, fix_T=True, t_row_sum=1.0, w_row_sum=1.0)),
+    # round 4: what nmf(group=) still refused.  nndsvdar: one draw per zero of the WHOLE W (initialization.py:147-152) -- every rank
+    # draws the whole sequence and keeps its rows' stretch; the weighted start (nmf.py:841-843 factorises W_mat .* X) through a scratch
+    # handle under the same group; tf-idf + normalisation on the device with the document frequencies all-reduced (matrixops.py:166-179);
+    # per-row weights (nmf.py:335-344) with their refit (nmf.py:531-539) as a fold-in under the same group
+    'start_nndsvdar': (1501, 700, 6, 3, False, 'float64', dict(_init='nndsvdar', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'start_weighted_nndsvd': (1201, 515, 5, 3, True, 'float64', dict(_init='nndsvd', t_row_sum=1.0, reset_topic_method=None)),
+    'preprocess_tfidf_normalize': (1501, 700, 6, 3, False, 'float64', dict(_counts=True, preprocess={'tfidf': True, 'normalize': True},
+                                                                          project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),
+    'row_weights_with_refit': (1000, 400, 5, 3, False, 'float64', dict(_w_row=True, w_row_sum=1.0, project_T_each_iter=True, t_row_sum=1.0)),
 }
 
 
@@ -77,6 +86,12 @@ def nmf_inputs(name):
     X, M, W0, T0 = _problem(n, d, k, weighted, np.dtype(store))
     init = flags.pop('_init', None)
     keep_T = flags.pop('_T_in', False)
+    if flags.pop('_counts', False):       # term counts with many zeros (tf-idf is trivial on a dense positive matrix)
+        X = np.random.RandomState(5).poisson(0.4 * X / X.mean()).astype(np.dtype(store))
+        W0, T0 = _problem(n, d, k, False, np.dtype(store), seed=3)[2:]
+        T0 = T0 / T0.sum(1, keepdims=True)
+    if flags.pop('_w_row', False):        # per-row weights, a column vector as the reference broadcasts it (nmf.py:337)
+        flags['w_row'] = 0.5 + np.random.RandomState(6).rand(n, 1)
     held_out = None
     if flags.pop('_early_stop', False):
         # 5 % of the observed entries are held out of the fit (mask 0 there) and scored after every sweep
@@ -142,6 +157,8 @@ def case_group_host_transport(out, name):
             np.random.seed(12345)         # only rank 0's generator may matter for 'random' resets
         if callable(kw.get('early_stop')):
             kw['early_stop'] = held_out_score(kw['early_stop'].all_entries, lo, hi)      # this rank's rows, local indices
+        if kw.get('w_row') is not None:
+            kw['w_row'] = kw['w_row'][lo:hi]                                            # this rank's rows
         with RowGroup.over_torch(hi - lo) as grp:
             assert (grp.row_lo, grp.n_global) == (lo, n)
             r = nmf_mod.nmf(X[lo:hi], k, W_mat=None if M is None else M[lo:hi], W_in=W0[lo:hi] if len(W0) else [], T_in=T0, group=grp, **kw)

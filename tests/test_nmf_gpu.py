@@ -301,8 +301,17 @@ def test_gaussian_mechanism_against_the_reference():
         r = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, W_mat=M, **kw)
         assert relfro(r['W'], g[name + '_W']) < 1e-8 and relfro(r['T'], g[name + '_T']) < 1e-8, \
             (name, relfro(r['W'], g[name + '_W']), relfro(r['T'], g[name + '_T']))
-    with pytest.raises(NotImplementedError):
-        nmf_mod.nmf(cases[0][1], k, W_in=W0, T_in=T0, fix_W=True, max_iter=1, eps_gauss_t=1.0, delta_gauss_t=0.1)
+    # W fixed (round 4: stepped like any other configuration; the oracle comparison is in test_store_gradients_matches_the_oracle).
+    # Noise far above the signal drives a denominator to zero: the reference's error, at the same topic as the oracle
+    from oracle import rri_oracle as orc
+    errs = []
+    for f in (lambda **kw: orc.nmf(np.array(cases[0][1], dtype=np.float64), k, W_in=np.array(W0, dtype=np.float64), T_in=np.array(T0, dtype=np.float64), **kw),
+              lambda **kw: nmf_mod.nmf(cases[0][1], k, W_in=W0, T_in=T0, **kw)):
+        np.random.seed(5)
+        with pytest.raises(ValueError, match='unbounded') as ei:
+            f(fix_W=True, max_iter=1, eps_gauss_t=1.0, delta_gauss_t=0.1)
+        errs.append(str(ei.value))
+    assert 'unbounded' in errs[0] and 'unbounded' in errs[1]
 
 
 def test_store_gradients_matches_the_oracle():
@@ -349,8 +358,23 @@ def test_store_gradients_matches_the_oracle():
     assert 'numer_W' not in nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, ind_rows_to_store=rows)
     fixed = nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, fix_T=True, store_gradients=True)
     assert fixed['numer_W'][0].size == 0
-    with pytest.raises(NotImplementedError):
-        nmf_mod.nmf(X, k, W_in=W0, T_in=T0, max_iter=1, fix_W=True, store_gradients=True)
+    # round 4: W fixed (only the T rows step, the kept columns take their scale, nmf.py:450-452) and k = 1 -- the reference's loop
+    # has no limit there (nmf.py:417-456); plain and weighted, with the sums stored and with the Gaussian mechanism on them
+    for name, Wm, kk, kw in (('W fixed', None, k, dict(fix_W=True)), ('W fixed, topic model', None, k, dict(fix_W=True, **tm)),
+                             ('W fixed, weighted', M, k, dict(fix_W=True, t_row_sum=1.0, reset_topic_method=None)),
+                             ('k = 1', None, 1, {}), ('k = 1, weighted', M, 1, dict(t_row_sum=1.0, reset_topic_method=None))):
+        Xc = X * Wm if Wm is not None else X
+        Wk, Tk = W0[:, :kk].copy(), T0[:kk].copy()
+        a = orc.nmf(Xc.copy(), kk, W_in=Wk.copy(), T_in=Tk.copy(), W_mat=Wm, max_iter=3, store_gradients=True, **kw)
+        b = nmf_mod.nmf(Xc, kk, W_in=Wk, T_in=Tk, W_mat=Wm, max_iter=3, store_gradients=True, **kw)
+        for it in a['numer_W']:
+            assert relfro(b['numer_W'][it], a['numer_W'][it]) < 1e-9 and relfro(b['denom_W'][it], a['denom_W'][it]) < 1e-9, (name, it)
+        assert relfro(b['W'], a['W']) < 1e-8 and relfro(b['T'], a['T']) < 1e-8, name
+        np.random.seed(11)
+        a = orc.nmf(Xc.copy(), kk, W_in=Wk.copy(), T_in=Tk.copy(), W_mat=Wm, max_iter=2, eps_gauss_t=1e7, delta_gauss_t=0.5, **kw)
+        np.random.seed(11)
+        b = nmf_mod.nmf(Xc, kk, W_in=Wk, T_in=Tk, W_mat=Wm, max_iter=2, eps_gauss_t=1e7, delta_gauss_t=0.5, **kw)
+        assert relfro(b['W'], a['W']) < 1e-7 and relfro(b['T'], a['T']) < 1e-7, (name, 'Gaussian mechanism', relfro(b['W'], a['W']), relfro(b['T'], a['T']))
     # the single-step helper the reference's test file imports (nmf.py:633-715)
     for Wm in (None, M):
         Xc = X * Wm if Wm is not None else X

@@ -42,6 +42,15 @@ for name, dt in (('pattern-only, float64 residual', np.float64), ('pattern-only,
         e.sweep(1)
         out[name] = (e.get_W(), e.get_T(), e.objective())
 Xh = A.toarray().astype(np.float64)
+# round 4: the dense handles too (bit-packed mask; ONE read-modify-write pass per topic step + the mask-only correction)
+for name, dt in (('dense, float64 residual', np.float64), ('dense, fp32 residual (what bench.py --config c5 times)', np.float32)):
+    with RRIEngine(N, D, K, dtype=dt, weighted=True) as e:
+        e.upload_X(Xh if dt == np.float64 else Xh.astype(dt))
+        e.upload_mask(Mh if dt == np.float64 else Mh.astype(dt))
+        e.set_W(W0); e.set_T(T0); e.set_params(**flags)
+        e.sweep(1)
+        out[name] = (e.get_W(), e.get_T(), e.objective())
+print('device runs done; the oracle sweep takes ~5 minutes', flush=True)
 t0 = time.perf_counter()
 with threadpool_limits(limits=16):
     ref = orc.nmf(Xh, K, W_in=W0.copy(), T_in=T0.copy(), W_mat=Mh, max_iter=1, eps_stop=-1, compute_obj_each_iter=True, **flags)

@@ -6,11 +6,13 @@
 //     numer_T[j] = sum_i w_i M_ij (X - W_{-t}T)_ij = a_j + t_j nw_j ,  a = w^T E ,  nw = (w^2)^T M
 //     numer_W[i] = b_i + w_i nt_i ,  b = E' t' ,  nt = M (t'^2) ,  E' = E - M .* (w dt^T)
 //     E''        = E' - M .* (dw t'^T)
-// Per topic step two passes over (E, M):
-//   pass B  reads E, M; applies the pending dt correction on the fly; row products b, nt      (no write)
-//   pass C  reads E, M; applies both corrections; writes E; column sums a, nw of the NEXT topic
-// = 5 n d s bytes per topic step (4 n d s + 1 for the rewrite).  E is refreshed from X, W, T
-// (k_resid) once per sweep, so storage rounding of E never accumulates over more than k updates.
+// Dense handles, round 4: ONE read-modify-write pass over (E, M) per topic step (k_wpass<Y, Z, UPD2, WRITE>) -- it folds the
+// W-column term of the step before and this step's T-row term into E, writes E, and takes the row products b, nt AND the
+// column sums of the next topic; the term the W update then leaves pending reaches those sums through a pass over the mask
+// alone (k_wmcorr; see "one read-modify-write pass" below).  (2 + 2/32) n d s bytes per topic step with a bit-packed mask.
+// Rounds 1-3 (RRI_WPASS_ONE=0): pass B reads E, M and takes the row products, pass C applies both corrections, writes E and
+// takes the next column sums: (3 + 2/32) n d s.  E is refreshed from X, W, T (k_resid) once per sweep either way, so the
+// storage rounding of E never accumulates over more than k updates.
 #pragma once
 #include "rri_kernels.hpp"
 

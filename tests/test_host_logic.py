@@ -95,10 +95,8 @@ def test_nmf_host_checks_before_device_work():
         nmf(X, 3, W_in=W0[:, :2], T_in=T0)
     with pytest.raises(ValueError, match='T_in has wrong dimensions'):
         nmf(X, 3, W_in=W0, T_in=T0[:, :5])
-    with pytest.raises(NotImplementedError):      # so does store_gradients
-        nmf(X, 3, W_in=W0, T_in=T0, store_gradients=True, fix_W=True)
-    with pytest.raises(NotImplementedError):      # the Gaussian mechanism steps topic by topic: both halves free
-        nmf(X, 3, W_in=W0, T_in=T0, eps_gauss_t=1.0, delta_gauss_t=0.1, fix_W=True)
+    # (store_gradients and the Gaussian mechanism with W fixed or k = 1 used to be refused here; since round 4 they step on the
+    # device like every other configuration -- tests/test_nmf_gpu.py::test_store_gradients_matches_the_oracle)
     Wkeep, Tkeep = W0.copy(), T0.copy()
     assert np.array_equal(W0, Wkeep) and np.array_equal(T0, Tkeep)   # caller arrays untouched
 

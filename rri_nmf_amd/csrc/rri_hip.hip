@@ -437,6 +437,9 @@ struct TimedScope {
 // geometry of k_pass, fixed per process (env RRI_PASS_UNROLL / RRI_PASS_NT)
 int g_pass_unroll = 8, g_pass_nt = -1, g_pass_rs = 1;   // RS: LDS row sums (needs unroll 8).  nt: -1 = per handle (non-temporal
                                                         // loads where X cannot stay in the caches, plain loads where it can)
+int g_pass_dma_sub = 0;       // RRI_PASS_DMA_SUB: row blocks per workgroup of the ring kernel (0: ~1024 workgroups)
+int g_pass_dma = 0;           // RRI_PASS_DMA=1: the read-only pass through the LDS-DMA ring (k_pass_dma).  OFF by default: the same bits as
+                              // k_pass, but between +3 % and -9 % in time by box, process and geometry (profiles/r04_pass_dma_ab.log)
 int g_pass_unroll_upd = 16;   // rows in flight of the read-modify-write passes (RRI_PASS_UNROLL set: follows it)
 int g_wpass_uc = 8;      // RRI_WPASS_UC: rows in flight of the writing weighted pass with a bit-packed mask: 8 (one mask word per
                          // chunk; +1.3 % at C5 over 4, 16 falls to one wave per SIMD: profiles/r02_weighted_pass_variants.log) or 4
@@ -489,9 +492,52 @@ struct LaunchX {
                            // stay in the DRAM pages that are open
                            ((g_pass_interleave == 1 || (g_pass_interleave < 0 && (c->npanels * c->nrb <= 1024 || UPD > 0))) ? c->nrb : 0) | (g_pass_rot << 27));
     }
+    // the read-only pass through the LDS-DMA ring (k_pass_dma), opt-in (RRI_PASS_DMA=1): where the ring and the row-dot slots fit
+    // the LDS and X's rows are 16-byte aligned
+    // A workgroup of the ring kernel walks `sub` consecutive row blocks of the handle's geometry as ONE stream (the ring stays full
+    // across them) and still leaves one row of column sums per row block: Ypart / Zpart -- and every sum in them -- are exactly
+    // what k_pass leaves.  (The hope was ~1024 long workgroups: measured 0.663 against 0.661 ms for the register kernel with two
+    // blocks per workgroup, 0.72 with three, 0.671 with four -- profiles/r04_pass_dma_ab.log.)  The row-dot slots of the sub blocks
+    // must fit the LDS next to the 64 KiB ring.
+    static int pass_dma_sub(const rri_ctx* c, bool interleaved) {
+        if (interleaved) return 1;
+        if (g_pass_dma_sub > 0) return std::max(1, std::min(g_pass_dma_sub, (int)(2200 / std::max(c->rpb, 1))));
+        const int want = (int)std::max<i64>(1, ((i64)c->npanels * c->nrb + 512) / 1024);
+        return std::max(1, std::min(want, 2200 / std::max(c->rpb, 1)));
+    }
+    static size_t pass_dma_shmem(const rri_ctx* c, int sub) { return (size_t)4 * PASS_DMA_SLOTS * 1024 + 5 * (size_t)sub * c->rpb * sizeof(double); }
+    static bool pass_dma(const rri_ctx* c, i64 ldp) {
+        if (g_pass_dma == 0 || g_pass_unroll != 8 || !g_pass_rs) return false;
+        if (pass_dma_shmem(c, 1) > 150 * 1024 || ldp % c->VN != 0 || c->rpb % PASS_DMA_CHUNK != 0) return false;
+        return g_pass_dma == 1;
+    }
+    template <bool DO_Y, bool DO_Z, bool NT>
+    static void pass_dma_k(rri_ctx* c, const void* Xp, i64 ldp, const double* trow, const double* wc, const TgramJob& job) {
+        static bool attr_set[64] = {};   // per instantiation and device
+        const int dv = c->device & 63;
+        if (!attr_set[dv]) {
+            // (the kernel also has 320 bytes of static LDS for its side job: dynamic + static must stay within the CU's 160 KiB)
+            (void)hipFuncSetAttribute((const void*)k_pass_dma<SX, DO_Y, DO_Z, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            attr_set[dv] = true;
+        }
+        const int ncols = (int)std::min<i64>(ldp, c->LD);
+        const bool il = g_pass_interleave == 1 || (g_pass_interleave < 0 && c->npanels * c->nrb <= 1024);
+        const int sub = pass_dma_sub(c, il);
+        const int ngroups = (c->nrb + sub - 1) / sub;
+        hipLaunchKernelGGL((k_pass_dma<SX, DO_Y, DO_Z, NT>), dim3(c->npanels * ngroups + job.nblocks), dim3(256), pass_dma_shmem(c, sub),
+                           c->stream, (const SX*)Xp, ldp, (int)c->n, ncols, trow, wc, c->Ypart, c->Zpart, c->LD, c->rpb,
+                           c->npanels, (const DevState*)c->st, job, il ? c->nrb : 0, sub, c->nrb);
+    }
     template <bool DO_Y, bool DO_Z, int UPD>
     static void pass_cfg(rri_ctx* c, void* Xp, i64 ldp, const double* trow, const double* wc, const Upd& u = Upd{},
                          const TgramJob& job = TgramJob{}) {
+        if constexpr (UPD == 0) {
+            if (pass_dma(c, ldp) && ((uintptr_t)Xp) % 16 == 0) {
+                if (pass_nt(c)) pass_dma_k<DO_Y, DO_Z, true>(c, Xp, ldp, trow, wc, job);
+                else pass_dma_k<DO_Y, DO_Z, false>(c, Xp, ldp, trow, wc, job);
+                return;
+            }
+        }
         if (UPD > 0 && g_pass_unroll_upd == 16) {
             // the read-modify-write variants: 16 rows in flight per wave, row dots by DPP wave sums -- 0.665 against 0.639
             // of 8 TB/s for the 8-row LDS row-sum variant at C3 (profiles/r02_residual_schedule_geometry.log)
@@ -1789,6 +1835,10 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_WPASS_ONE")) g_wpass_one = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_UNROLL")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) { g_pass_unroll = v; g_pass_unroll_upd = v; } }
     if (const char* e = getenv("RRI_PASS_NT")) g_pass_nt = atoi(e) != 0 ? 1 : 0;
+    g_pass_dma = 0;
+    if (const char* e = getenv("RRI_PASS_DMA")) g_pass_dma = atoi(e) != 0 ? 1 : 0;
+    g_pass_dma_sub = 0;
+    if (const char* e = getenv("RRI_PASS_DMA_SUB")) g_pass_dma_sub = std::max(0, atoi(e));
     if (const char* e = getenv("RRI_PASS_RS")) g_pass_rs = atoi(e) != 0;
     if (const char* e = getenv("RRI_OBJ_DIRECT")) g_obj_direct = atoi(e) != 0;
     if (const char* e = getenv("RRI_PASS_IL")) g_pass_interleave = atoi(e) != 0 ? 1 : 0;

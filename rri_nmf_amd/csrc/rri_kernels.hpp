@@ -278,6 +278,164 @@ __global__ __launch_bounds__(256) void k_pass(typename std::conditional<(UPD > 0
 }
 
 // =========================================================================================
+// k_pass_dma: the read-only pass (UPD = 0) with its rows staged through a per-wave LDS ring that LDS-DMA fills
+// (global_load_lds_dwordx4: HBM -> LDS with no VGPR destination), round 4.  Same geometry, same arithmetic in the same order
+// as k_pass<.., U = 8, RS = true> -- the sums are bit-identical -- but the loads of the next two chunks are in flight while a
+// chunk is worked on, at no cost in registers: S = 16 slots of 1 KiB (one row of the wave's panel each), C = 8 rows per chunk,
+// counted s_waitcnt vmcnt(8) instead of a drain.  OPT-IN (RRI_PASS_DMA=1), not the default: in the probe, beside k_pass on the same
+// buffer in one process (tools/lds_dma_probe.hip, profiles/r04_lds_dma_probe*.log), it was +1.5 ... +6 % at 100000 x 10000; inside the
+// library's sweep, engines made alternately in one process (profiles/r04_pass_dma_ab.log), it ranged from +3 % to -9 % by box,
+// process and workgroup geometry -- nowhere near the 0.61 ms that would have justified inline asm in the roofline kernel.  Kept as
+// the record of the attempt and as a tested, bit-identical alternative.
+// What it takes:
+//   * the LDS-DMA and its waits are inline asm (M0 carries the LDS base of a wave-instruction: saved and restored inside the
+//     statement; hipcc does not count asm loads, so the waits are ours);
+//   * ordinary loads issued before the loop (the T slice) must be CONSUMED before the first DMA: hipcc defers their wait to
+//     the first use, which sits inside the loop, and that vmcnt(0) would drain the ring on every iteration;
+//   * the 8 row dots of a chunk go through an LDS tile (wave_rowsum8_*) laid over the chunk's own ring slots, which are free
+//     between the reads of the chunk and their refill -- with six DPP steps per row the kernel was bound by its vector ALU.
+// LDS per workgroup: 64 KiB of ring + (4 + 1) rpb doubles; one or two workgroups per CU, which is enough: the ring, not the
+// occupancy, keeps the bytes in flight.
+// =========================================================================================
+template <bool NT>
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int PASS_DMA_SLOTS = 16, PASS_DMA_CHUNK = 8;
+template <typename SX, bool DO_Y, bool DO_Z, bool NT>
+__global__ __launch_bounds__(256) void k_pass_dma(const SX* __restrict__ X, i64 ldx, int n, int ncols,
+                                                  const double* __restrict__ trow, const double* __restrict__ wcol,
+                                                  double* __restrict__ Ypart, double* __restrict__ Zpart, i64 ldz, int rpb,
+                                                  int npg, const DevState* __restrict__ st, const TgramJob job, int nrb_il,
+                                                  int sub, int nrb) {
+    // sub: a workgroup walks `sub` consecutive row blocks (rb0 .. rb0 + sub - 1, contiguous rows; sub = 1 with interleaved chunks) as
+    // one stream and leaves one row of Zpart per row block, as k_pass does: the ring stays full across the blocks
+    typedef XVec<SX> XV;
+    typedef typename XV::type V;
+    constexpr int VN = XV::N;
+    constexpr int PW = 64 * VN;
+    constexpr int S = PASS_DMA_SLOTS, C = PASS_DMA_CHUNK, K = S / C;
+    if (st->halt) return;
+    if ((int)blockIdx.x < job.nblocks) {
+        __shared__ double jscratch[40];
+        tgram_block(job.T, job.ldt, job.d, job.k, job.t, (int)blockIdx.x % job.k, (int)blockIdx.x / job.k, job.nsplit,
+                    job.Ttpart, job.tpart, job.ntb, job.finish, job.sweep, job.p, job.st, jscratch);
+        return;
+    }
+    const int bid = (int)blockIdx.x - job.nblocks;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int rows = sub * rpb;                                           // local rows of this workgroup
+    V* ring = reinterpret_cast<V*>(smem);                                 // [4 waves][S][64 lanes]
+    double* ysh = reinterpret_cast<double*>(smem + 4 * S * 1024);         // [4][rows]
+    double* wsh = ysh + 4 * rows;                                         // [rows]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pg = bid % npg, rb = (bid / npg) * sub;                     // rb: the first row block of the group
+    auto grow = [&](int li) -> int { return nrb_il > 0 ? ((li / C) * nrb_il + rb) * C + (li % C) : rb * rpb + li; };
+    if (DO_Z) {
+        for (int i = threadIdx.x; i < rows; i += 256) {
+            const int g = grow(i);
+            wsh[i] = g < n ? wcol[g] : 0.0;
+        }
+        __syncthreads();
+    }
+    const int col = (pg * 4 + wave) * PW + lane * VN;
+    if ((pg * 4 + wave) * PW >= ncols) {                // wave-uniform: a panel beyond the matrix
+        if (DO_Y)
+            for (int i = lane; i < rows; i += 64) ysh[wave * rows + i] = 0.0;
+    } else {
+        const bool ok = col < ncols;
+        const int colc = ok ? col : 0;                  // lanes beyond the last column load (and ignore) column 0
+        double tv[VN], zacc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            zacc[e] = 0.0;
+            tv[e] = (DO_Y && ok) ? trow[col + e] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) asm volatile("" ::"v"(tv[e]));      // see the header: consumed before the first DMA
+        V* myring = ring + (size_t)wave * S * 64;
+        // LDS byte offset of the wave's ring (address space 3 pointers are 32-bit offsets into the workgroup's allocation)
+        const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (unsigned)wave * S * 1024u;
+        int nchunks = 0;                                // chunks of this block that start inside the matrix
+        for (int l0 = 0; l0 < rows; l0 += C) { if (grow(l0) < n) nchunks = l0 / C + 1; else break; }
+        const int cpb = rpb / C;                        // chunks per row block (rpb is a multiple of C)
+        auto issue = [&](int q) {                       // chunk q of the block into the ring slots (q mod K) C ...
+            const int r = grow(q * C);
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                const int rr = min(r + u, n - 1);       // rows beyond the matrix: the last row again (ignored below)
+                glds16<NT>(X + (i64)rr * ldx + colc, ring_base + (unsigned)(((q % K) * C + u) * 1024));
+            }
+        };
+        for (int q = 0; q < K && q < nchunks; ++q) issue(q);
+        for (int q = 0; q < nchunks; ++q) {
+            // chunk q must have landed: K - 1 chunks of loads were issued after it (fewer near the end: wait for all)
+            if (q + K <= nchunks) wait_vmcnt<C * (K - 1)>();
+            else wait_vmcnt<0>();
+            const int l0 = q * C, r = grow(l0);
+            V x[C];
+#pragma unroll
+            for (int u = 0; u < C; ++u) x[u] = myring[((q % K) * C + u) * 64 + lane];
+            double* tile = reinterpret_cast<double*>(myring + ((q % K) * C) * 64);     // 8 x 72 doubles of the 8 KiB just read
+            asm volatile("" ::: "memory");             // the tile aliases the ring: no store to it may move above the reads
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                const int rr = r + u;
+                double wv = 0.0;
+                if (DO_Z && rr < n) wv = wsh[l0 + u];
+                double xe[VN];
+                XV::unpack(x[u], xe);
+                double yp = 0.0;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    if (DO_Y) yp = fma(xe[e], tv[e], yp);
+                    if (DO_Z) zacc[e] = fma(wv, xe[e], zacc[e]);
+                }
+                if (!(rr < n && ok)) yp = 0.0;          // (k_pass zeroes the loaded vector there: the same zero partial)
+                if constexpr (DO_Y) wave_rowsum8_park(tile, u, lane, yp);
+            }
+            if constexpr (DO_Y) {
+                const double tot = wave_rowsum8_finish(tile, lane);
+                if ((lane & 7) == 0) ysh[wave * rows + l0 + (lane >> 3)] = tot;
+            }
+            // the slots are free once the reads above have returned (their values were consumed): refill them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (q + K < nchunks) issue(q + K);
+            // the last chunk of a row block (or of the workgroup): its column sums are complete
+            if (DO_Z && ((q + 1) % cpb == 0 || q + 1 == nchunks)) {
+                const int rbq = rb + q / cpb;
+                if (ok && rbq < nrb) {
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) Zpart[(i64)rbq * ldz + col + e] = zacc[e];
+                }
+#pragma unroll
+                for (int e = 0; e < VN; ++e) zacc[e] = 0.0;
+            }
+        }
+        // row blocks of the group that lie wholly beyond the matrix cannot occur (nrb = ceil(n / rpb)), but a group may end early
+        if (DO_Y)
+            for (int i = nchunks * C + lane; i < rows; i += 64) ysh[wave * rows + i] = 0.0;
+    }
+    if (DO_Y) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows; i += 256) {
+            const int g = grow(i);
+            if (g < n) Ypart[(i64)pg * n + g] = (ysh[i] + ysh[rows + i]) + (ysh[2 * rows + i] + ysh[3 * rows + i]);
+        }
+    }
+}
+
+// =========================================================================================
 // k_colsums: column sums of X against NV row-vectors at once (X^T Q for the randomized SVD behind NNDSVD,
 // initialization.py:105): the geometry of k_pass -- 4 waves = 4 adjacent 1 KiB panels x a row block, 4 rows in
 // flight -- with NV accumulator sets per lane, so X is read once per NV vectors instead of once per vector.

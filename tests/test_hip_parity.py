@@ -463,3 +463,38 @@ def test_bench_line_keeps_its_contract():
     sc = j['rank1_update']['schedule']
     assert sc['sweeps_per_s'] > 0 and max(sc['vs_default_schedule_after_4_sweeps'].values()) < 1e-4, sc
     assert j['rank1_update']['achieved'] > 0
+
+
+@pytest.mark.parametrize('shape', [(700, 333, 6), (257, 1030, 5), (1501, 100, 3), (5003, 1000, 22), (64, 4100, 2), (9, 7, 2), (300, 500, 1)])
+@pytest.mark.parametrize('store', [np.float32, np.float64])
+def test_the_lds_dma_pass_gives_the_register_pass_its_bits(monkeypatch, shape, store):
+    """k_pass_dma (round 4): the read-only pass with its rows staged through an LDS ring that LDS-DMA fills.  Same arithmetic in
+    the same order as k_pass, so the SAME BITS -- on ragged shapes (rows not a multiple of the chunk, columns not a multiple of
+    a lane's vector or of a panel, fewer columns than one wave covers, more panels than one workgroup), both storage types,
+    plain and topic-model flags, fixed halves, with and without interleaved row chunks.  The library takes the ring by itself only
+    where X streams from HBM; RRI_PASS_DMA=1 forces it here."""
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = shape
+    X = planted_X(n, d, k, seed=n + d, dtype=store)
+    W0, T0 = scaled_init(X, k, seed=3)
+    T0s = T0 / T0.sum(1, keepdims=True)
+    monkeypatch.setenv('RRI_ONCHIP', '0')          # the launch-per-phase schedule: that is where the pass runs
+
+    def run(dma, il, flags, T, sub='0'):
+        monkeypatch.setenv('RRI_PASS_DMA', dma)
+        monkeypatch.setenv('RRI_PASS_IL', il)
+        monkeypatch.setenv('RRI_PASS_DMA_SUB', sub)       # row blocks a workgroup of the ring kernel walks as one stream
+        monkeypatch.setenv('RRI_PASS_WGS', '64' if sub != '0' else '2048')   # several row blocks even at these sizes
+        with RRIEngine(n, d, k, dtype=store) as e:
+            e.upload_X(X), e.set_W(W0), e.set_T(T), e.set_params(**flags)
+            e.sweep(3)
+            return e.get_W(), e.get_T(), e.objective()
+
+    for flags, T in ((dict(), T0), (dict(project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0), T0s), (dict(fix_W=True), T0),
+                     (dict(reg_w_l1=0.01, reg_t_l2=0.02), T0)):
+        for il in ('0', '1'):
+            a, b = run('1', il, flags, T), run('0', il, flags, T)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (flags, il, relfro(a[0], b[0]), relfro(a[1], b[1]))
+        # three row blocks per workgroup (contiguous rows), the last group ragged: still one row of column sums per row block
+        a, b = run('1', '0', flags, T, sub='3'), run('0', '0', flags, T, sub='3')
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (flags, 'sub 3', relfro(a[0], b[0]), relfro(a[1], b[1]))

@@ -167,6 +167,11 @@ struct rri_ctx {
     // dense weighted, one read-modify-write pass per topic step: the column sums a pass leaves for the next T row lack the
     // rank-one term of the W update that follows it; k_wmcorr takes that term from the mask alone (Cpart: its partials)
     double* Cpart = nullptr;
+    double* N2part = nullptr;   // [cpart_rows x LD] nw = (w^2)^T M as row-block partials, where k_wmcorr_cols takes it (nw_from_mask)
+    unsigned* Mcols = nullptr;  // the packed 0/1 mask once more with the rows in the bits (k_wmcorr_cols), built on first use
+    bool nw_mask = false;       // this T-row step's nw was taken by k_wmcorr_cols (N2part), not by the pass (Z2part)
+    bool mcols_tried = false;   // ... or found not worth it (dense mask, no memory)
+    double mask_density = 1.0;
     int cpart_rows = 0;         // rows allocated in Cpart
     bool wcorr = false;         // the T-row step being enqueued subtracts T[wcorr_topic,:] .* sum_b Cpart[b]
     int wcorr_topic = 0, wcorr_nrb = 0;
@@ -447,6 +452,9 @@ int g_wpass_ud = 4;      // RRI_WPASS_UD: rows in flight of the one-pass weighte
                          // BASELINE config 5 against 1.553 ms for 8 (LDS row sums, 240 VGPRs, 2 waves per SIMD) and 1.618 ms for 8 with
                          // DPP row sums, engines made alternately in one process (profiles/r04_wpass_one_variants.log)
 int g_wpass_occ4 = 1;    // RRI_WPASS_OCC4=0: the one-pass step at the compiler's own register count (130: 3 waves per SIMD)
+int g_wnw_mask = 1;      // RRI_WNW_MASK=0: the one-pass step keeps taking nw = (w^2)^T M in the read-modify-write pass on a sparse 0/1 mask too
+int g_wmcorr_wgs = 16;   // RRI_WMCORR_WGS: workgroups per CU of k_wmcorr_cols (4: 60 us, 8: 48, 16: 46, 32: 44 at BASELINE config 5)
+int g_wmcorr_cols = 1;   // RRI_WMCORR_COLS=0: the mask-only correction always walks every bit (k_wmcorr), also on a sparse mask
 int g_wmcorr_skip = 1;   // RRI_WMCORR_SKIP=0: k_wmcorr does not test the row factors for zero
 int g_wpass_one = 1;     // RRI_WPASS_ONE=0: the dense weighted flavour in two passes per topic step (read; read-modify-write), as rounds 1-3
 int g_wpass_il = -1;     // RRI_WPASS_IL: 1 / 0 = interleaved / contiguous row chunks in every weighted pass; default: the writing ones
@@ -584,10 +592,18 @@ struct LaunchX {
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, bool MBITS, int U, bool RS>
     static void wpass_k(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
                         const double* a2, const double* b2) {
+        if constexpr (DO_Z && MBITS) {      // a sparse 0/1 mask: nw comes from k_wmcorr_cols, the pass leaves Z2part alone
+            if (nw_from_mask(c)) { wpass_k2<DO_Y, DO_Z, UPD2, WRITE, MBITS, U, RS, false>(c, trow, wc, a1, b1, a2, b2); return; }
+        }
+        wpass_k2<DO_Y, DO_Z, UPD2, WRITE, MBITS, U, RS, DO_Z>(c, trow, wc, a1, b1, a2, b2);
+    }
+    template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, bool MBITS, int U, bool RS, bool DO_Z2>
+    static void wpass_k2(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
+                         const double* a2, const double* b2) {
         const int ncols = (int)std::min<i64>(c->ldx, c->LD);
         if constexpr (DO_Y && WRITE && U == 4) {
-            if (g_wpass_occ4) {     // the one-pass step, 4 rows in flight: the build for four waves per SIMD
-                hipLaunchKernelGGL((k_wpass_occ4<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS>), dim3(c->npanels * c->nrb),
+            if (g_wpass_occ4 && (DO_Z2 || !DO_Z)) {     // the one-pass step, 4 rows in flight: the build for four waves per SIMD
+                hipLaunchKernelGGL((k_wpass_occ4<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS, DO_Z2>), dim3(c->npanels * c->nrb),
                                    dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
                                    (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
                                    wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
@@ -595,7 +611,7 @@ struct LaunchX {
                 return;
             }
         }
-        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS>), dim3(c->npanels * c->nrb),
+        hipLaunchKernelGGL((k_wpass<SX, DO_Y, DO_Z, UPD2, WRITE, U, true, MBITS, RS, DO_Z2>), dim3(c->npanels * c->nrb),
                            dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
                            (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
                            wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
@@ -630,8 +646,52 @@ struct LaunchX {
     }
     // c = M^T (wn .* dw) as row-block partials in Cpart (k_wmcorr): the correction of the column sums a one-pass topic step
     // leaves behind.  Geometry: ~4 workgroups per CU, row blocks of a multiple of 64 rows, at most 4096 (32 KiB of LDS).
+    // the column-major copy of the packed mask, on first use (one-off: a kernel, a count, one synchronisation)
+    static bool mask_cols(rri_ctx* c) {
+        if (!c->Mbits || !g_wmcorr_cols) return false;
+        if (!c->mcols_tried) {
+            c->mcols_tried = true;
+            const i64 ng = (c->n + 31) / 32;
+            unsigned long long* cnt = nullptr;
+            if (hipMalloc((void**)&c->Mcols, (size_t)ng * c->LD * sizeof(unsigned)) != hipSuccess) { c->Mcols = nullptr; (void)hipGetLastError(); return false; }
+            if (hipMalloc((void**)&cnt, sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(c->Mcols); c->Mcols = nullptr; (void)hipGetLastError(); return false; }
+            (void)hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream);
+            hipLaunchKernelGGL(k_mask_cols_from_bits, dim3(4096), dim3(256), 0, c->stream, (const unsigned*)c->Mbits, c->ldb, c->n, c->Mcols,
+                               c->LD, cnt);
+            unsigned long long h = 0;
+            hipError_t e = hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            (void)hipFree(cnt);
+            if (e != hipSuccess) { (void)hipFree(c->Mcols); c->Mcols = nullptr; return false; }
+            c->mask_density = (double)h / ((double)c->n * (double)c->d);
+            if (c->mask_density > 0.12) { (void)hipFree(c->Mcols); c->Mcols = nullptr; }     // the dense-bit kernel is the cheaper one there
+        }
+        return c->Mcols != nullptr;
+    }
+    // the second column sum of a T-row step, nw = (w^2)^T M, from the mask-only kernel instead of the pass: dense handles on the
+    // one-pass schedule whose mask is 0/1 and sparse enough for the column-major copy
+    static bool nw_from_mask(rri_ctx* c) { return !c->sparse && g_wpass_one && g_wnw_mask && mask_cols(c); }
+    // dw == NULL: nothing pending, nw alone (nw_from_mask handles)
     static void wmcorr(rri_ctx* c, const double* wn, const double* dw) {
         TimedScope ts(c, 2);
+        if (mask_cols(c)) {     // a sparse 0/1 mask: the set bits only
+            const bool nw = nw_from_mask(c);
+            const int npg = (int)((c->LD + 255) / 256);
+            i64 nrb = std::min<i64>(256, std::max<i64>(1, (g_wmcorr_wgs * (i64)std::max(c->n_cu, 1) + npg - 1) / npg));
+            i64 rpb = std::min<i64>(2048, round_up((c->n + nrb - 1) / nrb, 32));
+            nrb = (c->n + rpb - 1) / rpb;            // <= cpart_rows (256, or n / 2048 where that is more: rri_create)
+            c->wcorr_nrb = (int)nrb;
+            const dim3 grid((unsigned)(npg * nrb));
+            const size_t sh = (size_t)rpb * sizeof(double) * ((dw && nw) ? 2 : 1);
+#define RRI_WMC(HD, NW_) hipLaunchKernelGGL((k_wmcorr_cols<HD, NW_>), grid, dim3(256), sh, c->stream, (const unsigned*)c->Mcols, c->LD, \
+                                            (int)c->n, (int)c->LD, wn, dw, c->Cpart, c->N2part, c->LD, (int)rpb, npg, (const DevState*)c->st)
+            if (dw && nw) RRI_WMC(true, true);
+            else if (dw) RRI_WMC(true, false);
+            else if (nw) RRI_WMC(false, true);
+#undef RRI_WMC
+            return;
+        }
+        if (!dw) return;
         const bool bits = c->Mbits != nullptr;
         const int npg = bits ? (int)((c->ldb + 255) / 256) : c->npanels;
         i64 nrb = std::min<i64>(256, std::max<i64>(1, (4 * (i64)std::max(c->n_cu, 1) + npg - 1) / npg));
@@ -717,6 +777,8 @@ struct LaunchX {
     // 0/1 masks are bit-packed (32 columns per word): the mask then costs 1/32 of its fp32 bytes per pass
     static rri_status pack_mask_if_binary(rri_ctx* c) {
         if (c->Mbits) { (void)hipFree(c->Mbits); c->Mbits = nullptr; }
+        if (c->Mcols) { (void)hipFree(c->Mcols); c->Mcols = nullptr; }
+        c->mcols_tried = false;
         if (const char* e = getenv("RRI_MASK_BITS")) if (atoi(e) == 0) return RRI_OK;
         hipError_t err = hipMemsetAsync(c->itmp, 0, sizeof(i64), c->stream);
         if (err != hipSuccess) return RRI_ERR_HIP;
@@ -1273,8 +1335,9 @@ void w_refresh(rri_ctx* c) {
 void w_reduce(rri_ctx* c, bool take_check = false, int sweep = 0, int pos = 0) {
     const int nb = (int)((c->LD + 63) / 64);
     const int chk = (take_check && c->pending_wcheck) ? 1 : 0;
-    hipLaunchKernelGGL(k_wreduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart, (const double*)c->Z2part, c->LD,
-                       c->nrb, c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
+    const bool nwm = c->nw_mask;     // (set by enqueue_wT_sums: the T-row step's nw lies in N2part, k_wmcorr_cols' row blocks)
+    hipLaunchKernelGGL(k_wreduce, dim3(nb), dim3(1024), 0, c->stream, (const double*)c->Zpart,
+                       (const double*)(nwm ? c->N2part : c->Z2part), c->LD, c->nrb, nwm ? c->wcorr_nrb : c->nrb, c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
                        (const double*)(c->T + (i64)c->wcorr_topic * c->LD), c->red, (const double*)c->Gpart, c->nwb256, c->k, chk,
                        c->pending_wcheck_topic, sweep, pos, kparams(c), c->st);
     if (chk) c->pending_wcheck = false;
@@ -1294,9 +1357,11 @@ void enqueue_wT_sums(rri_ctx* c, int t, bool fused = false, bool take_check = fa
     // dense handles: E -- and with it these sums, carried or just taken -- lacks the rank-one term of the last W update
     // (dw T[dw_topic,:]^T under the mask; the next pass folds it in).  Its share of the sums comes from the mask alone.
     c->wcorr = !c->sparse && c->dw_pending;
-    if (c->wcorr) {
-        c->wcorr_topic = c->dw_topic;
-        DISPATCH(c, L::wmcorr(c, wt_t, c->dwv));
+    c->nw_mask = false;
+    DISPATCH(c, c->nw_mask = L::nw_from_mask(c));      // sparse 0/1 mask: nw from the same mask-only launch (the passes skipped it)
+    if (c->wcorr || c->nw_mask) {
+        if (c->wcorr) c->wcorr_topic = c->dw_topic;
+        DISPATCH(c, L::wmcorr(c, wt_t, c->wcorr ? c->dwv : nullptr));
     }
     if (fused) return;       // reduced inside k_wtrow_small
     TimedScope ts(c, 2);
@@ -1312,8 +1377,8 @@ void enqueue_wT_solve(rri_ctx* c, int sweep, int t, bool fused = false) {
         if (fused) {
             const int nb = nb_small;
             hipLaunchKernelGGL(k_wtrow_small, dim3(nb), dim3(128), 0, c->stream, (const double*)c->T, c->LD, (int)c->d, t,
-                               (const double*)c->Zpart, (const double*)c->Z2part, c->LD, c->nrb,
-                               c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
+                               (const double*)c->Zpart, (const double*)(c->nw_mask ? c->N2part : c->Z2part), c->LD, c->nrb,
+                               c->nw_mask ? c->wcorr_nrb : c->nrb, c->wcorr ? (const double*)c->Cpart : (const double*)nullptr, c->wcorr_nrb,
                                (const double*)(c->T + (i64)c->wcorr_topic * c->LD), (const double*)c->Gpart,
                                c->nwb256, c->k, c->pending_wcheck ? 1 : 0, c->pending_wcheck_topic, sweep, c->red, c->xraw,
                                c->tpart, c->tpart_idx, kparams(c), c->st);
@@ -1828,6 +1893,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     g_wpass_one = 1;
     g_wpass_occ4 = 1;
     if (const char* e = getenv("RRI_WPASS_OCC4")) g_wpass_occ4 = atoi(e) != 0;
+    g_wmcorr_cols = 1;
+    g_wmcorr_wgs = 16;
+    g_wnw_mask = 1;
+    if (const char* e = getenv("RRI_WNW_MASK")) g_wnw_mask = atoi(e) != 0;
+    if (const char* e = getenv("RRI_WMCORR_WGS")) g_wmcorr_wgs = std::min(64, std::max(1, atoi(e)));
+    if (const char* e = getenv("RRI_WMCORR_COLS")) g_wmcorr_cols = atoi(e) != 0;
     g_wmcorr_skip = 1;
     if (const char* e = getenv("RRI_WMCORR_SKIP")) g_wmcorr_skip = atoi(e) != 0;
     g_wpass_ud = 4;
@@ -1977,9 +2048,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         CR(hipMalloc((void**)&c->Z2part, (size_t)c->nrb * c->LD * f8));
         CR(hipMemsetAsync(c->Z2part, 0, (size_t)c->nrb * c->LD * f8, c->stream));
         if (!c->sparse) {
-            c->cpart_rows = (int)std::max<i64>(256, (n + 4095) / 4096);
+            c->cpart_rows = (int)std::max<i64>(256, (n + 2047) / 2048);
             CR(hipMalloc((void**)&c->Cpart, (size_t)c->cpart_rows * c->LD * f8));
             CR(hipMemsetAsync(c->Cpart, 0, (size_t)c->cpart_rows * c->LD * f8, c->stream));
+            CR(hipMalloc((void**)&c->N2part, (size_t)c->cpart_rows * c->LD * f8));
+            CR(hipMemsetAsync(c->N2part, 0, (size_t)c->cpart_rows * c->LD * f8, c->stream));
         }
         CR(hipMalloc((void**)&c->dtv, (size_t)c->LD * f8));
         CR(hipMalloc((void**)&c->dwv, (size_t)n * f8));
@@ -2024,7 +2097,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->Cpart, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->Cpart, (void*)c->N2part, (void*)c->Mcols, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -2152,6 +2225,8 @@ rri_status rri_upload_mask_csr_pattern(rri_ctx* c, const int64_t* indptr, const 
     c->own_M = false;
     c->ldm = c->LD;
     if (c->Mbits) { (void)hipFree(c->Mbits); c->Mbits = nullptr; }
+    if (c->Mcols) { (void)hipFree(c->Mcols); c->Mcols = nullptr; }
+    c->mcols_tried = false;
     c->ldb = (c->LD + 3) / 4;
     const size_t words = (size_t)((c->n + 7) / 8) * c->ldb;
     HIPCHK(c, hipMalloc((void**)&c->Mbits, words * sizeof(unsigned)));

@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void k_csr_pattern_bits(const i64* __restrict_
 
 // Same block geometry as k_pass: 4 waves = 4 adjacent 1 KiB-wide panels x one row block.
 //   e' = e - m (a1_i b1_j + [UPD2] a2_i b2_j)      (a1,a2: per row, from LDS; b1,b2: per column, registers)
-//   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , Z2part = sum_i w_i^2 m
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
+//   DO_Y: Ypart = sum_j e' t_j , Y2part = sum_j m t_j^2     DO_Z: Zpart = sum_i w_i e' , [DO_Z2] Z2part = sum_i w_i^2 m
+//   (DO_Z2 = false: a sparse 0/1 mask, whose second sum the mask-only kernel k_wmcorr_cols takes beside its own)
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS, bool DO_Z2>
 __device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restrict__ M, i64 ldx, i64 ldm,
                                            const unsigned* __restrict__ Mb, i64 ldb, int n, int ncols,
                                            const double* __restrict__ trow, const double* __restrict__ wcol,
@@ -223,7 +224,8 @@ __device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restr
 #pragma unroll
                 for (int e = 0; e < VN; ++e) {
                     if (DO_Y) { yp = fma(xe[e], tv[e], yp); y2p = fma(me[e] * tv[e], tv[e], y2p); }   // (m t) t: t^2 is not kept in registers
-                    if (DO_Z) { zacc[e] = fma(wv, xe[e], zacc[e]); z2acc[e] = fma(wv2, me[e], z2acc[e]); }
+                    if (DO_Z) zacc[e] = fma(wv, xe[e], zacc[e]);
+                    if (DO_Z && DO_Z2) z2acc[e] = fma(wv2, me[e], z2acc[e]);
                 }
                 if (DO_Y) {
                     ys[u] = RS ? yp : wave_sum<double>(yp);
@@ -248,7 +250,7 @@ __device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restr
 #pragma unroll
             for (int e = 0; e < VN; ++e) {
                 Zpart[(i64)rb * ldz + col + e] = zacc[e];
-                Z2part[(i64)rb * ldz + col + e] = z2acc[e];
+                if (DO_Z2) Z2part[(i64)rb * ldz + col + e] = z2acc[e];
             }
         }
     } else if (DO_Y) {
@@ -273,15 +275,17 @@ __device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restr
         double *__restrict__ Ypart, double *__restrict__ Y2part, double *__restrict__ Zpart, double *__restrict__ Z2part, \
         i64 ldz, int rpb, int npg, const DevState *__restrict__ st, int nrb_il
 #define RRI_WPASS_PASS E, M, ldx, ldm, Mb, ldb, n, ncols, trow, wcol, a1v, b1v, a2v, b2v, Ypart, Y2part, Zpart, Z2part, ldz, rpb, npg, st, nrb_il
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS, bool DO_Z2 = DO_Z>
 __global__ __launch_bounds__(256) void k_wpass(RRI_WPASS_ARGS) {
-    wpass_body<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT, MBITS, RS>(RRI_WPASS_PASS);
+    wpass_body<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT, MBITS, RS, DO_Z2>(RRI_WPASS_PASS);
 }
 // The same pass compiled for four waves per SIMD (128 registers): the one-pass step with 4 rows in flight needs 130 as the
-// compiler allocates it freely and fits 128 without a spill when told to (8 rows in flight would spill 110).
-template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS>
+// compiler allocates it freely and fits 128 without a spill when told to (8 rows in flight would spill 110).  The step that
+// leaves nw to the mask-only kernel (DO_Z2 = false) needs 98 either way and runs as k_wpass (1.353 against 1.366 ms in one
+// process; built for FIVE waves, 96 registers and 2 spilled, 1.50 ms -- profiles/r04_wpass_one_variants.log).
+template <typename SX, bool DO_Y, bool DO_Z, bool UPD2, bool WRITE, int U, bool NT, bool MBITS, bool RS, bool DO_Z2 = DO_Z>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wpass_occ4(RRI_WPASS_ARGS) {
-    wpass_body<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT, MBITS, RS>(RRI_WPASS_PASS);
+    wpass_body<SX, DO_Y, DO_Z, UPD2, WRITE, U, NT, MBITS, RS, DO_Z2>(RRI_WPASS_PASS);
 }
 #undef RRI_WPASS_ARGS
 #undef RRI_WPASS_PASS
@@ -379,6 +383,93 @@ __global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ld
     }
 }
 
+// ---- the same correction on a SPARSE 0/1 mask: walk the set bits only -------------------------------------------------------
+// k_wmcorr spends three vector instructions on every mask bit, set or not: 10^9 of them at BASELINE config 5, where 5 % are set.
+// A second packed copy of the mask with the ROWS in the bits -- Mc[(row >> 5) * ldc + col], bit (row & 31): a lane owns one column
+// and a word holds 32 rows of it -- lets a lane find its set bits with count-trailing-zeros and add u[row] for those alone
+// (~7 instructions per SET bit; a wave runs as long as its fullest word).  Same sums in the same row order; used below 12 %
+// density (k_mask_cols_from_bits counts the bits), the dense-bit kernel above otherwise.  n d / 8 bytes more device memory.
+__global__ __launch_bounds__(256) void k_mask_cols_from_bits(const unsigned* __restrict__ Mb, i64 ldb, i64 n, unsigned* __restrict__ Mc,
+                                                             i64 ldc, unsigned long long* __restrict__ nnz) {
+    const i64 ngroups = (n + 31) >> 5;
+    const i64 total = ngroups * ldc;
+    unsigned long long cnt = 0;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 g = idx / ldc, col = idx - g * ldc;
+        unsigned out = 0u;
+        for (int q = 0; q < 4; ++q) {
+            const i64 rg = g * 4 + q;                    // 8-row group of the (8 rows x 4 columns)-per-word layout
+            if (rg * 8 >= n) break;
+            const unsigned word = Mb[rg * ldb + (col >> 2)] >> (int)(col & 3);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) out |= ((word >> (r * 4)) & 1u) << (q * 8 + r);
+        }
+        Mc[idx] = out;
+        cnt += (unsigned)__popc(out);
+    }
+    cnt = (unsigned long long)wave_sum_i32((int)cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nnz, cnt);
+}
+
+// HAS_DW: the correction c (Cpart).  NW: also nw_j = sum_i M_ij wn_i^2 (N2part) -- the second column sum of the T-row step is a
+// sum over the mask alone as well, and taking it here (one more LDS read and add per SET bit) spares the read-modify-write pass
+// its second set of accumulators and n_row_blocks x d doubles written there and read back by k_wreduce (125 MB each way at
+// BASELINE config 5).  Same sum in another (still fixed) order.
+template <bool HAS_DW, bool NW>
+__global__ __launch_bounds__(256) void k_wmcorr_cols(const unsigned* __restrict__ Mc, i64 ldc, int n, int ncols,
+                                                     const double* __restrict__ wn, const double* __restrict__ dw,
+                                                     double* __restrict__ Cpart, double* __restrict__ N2part, i64 ldz, int rpb,
+                                                     int npg, const DevState* __restrict__ st) {
+    static_assert(HAS_DW || NW, "nothing to take");
+    if (st->halt) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PS = (HAS_DW && NW) ? 2 : 1;       // doubles per row in LDS: {u, wn^2} | u | wn^2
+    double* ush = reinterpret_cast<double*>(smem);   // [rpb][PS], rpb a multiple of 32
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    const int row0 = rb * rpb;
+    for (int i = threadIdx.x; i < rpb; i += 256) {
+        const int g = row0 + i;
+        const double wv = g < n ? wn[g] : 0.0;
+        if (HAS_DW) ush[i * PS] = g < n ? wv * dw[g] : 0.0;
+        if (NW) ush[i * PS + (PS - 1)] = wv * wv;
+    }
+    __syncthreads();
+    const int col = (pg * 4 + wave) * 64 + lane;
+    if ((pg * 4 + wave) * 64 >= ncols) return;        // wave-uniform
+    const bool ok = col < ncols;
+    const i64 colc = ok ? col : 0;
+    const int g0 = row0 >> 5, g1 = min((n + 31) >> 5, (row0 + rpb) >> 5);
+    double acc = 0.0, acc2 = 0.0;
+    constexpr int UG = 8;
+    for (int g = g0; g < g1; g += UG) {
+        unsigned w[UG];
+#pragma unroll
+        for (int q = 0; q < UG; ++q) w[q] = Mc[(i64)min(g + q, g1 - 1) * ldc + colc];
+#pragma unroll
+        for (int q = 0; q < UG; ++q) {
+            if (g + q >= g1) break;                   // wave-uniform
+            const double* up = ush + ((g + q - g0) << 5) * PS;
+            unsigned wq = w[q];
+            while (wq) {                              // rows in ascending order, as the dense-bit kernel adds them
+                const int b = __builtin_ctz(wq);      // (four words walked at once into four sums: 83 us against 60 -- the predicated
+                wq &= wq - 1u;                        //  selects cost more than the shared waits save)
+                if constexpr (PS == 2) {
+                    const f64x2 v = *reinterpret_cast<const f64x2*>(up + 2 * b);
+                    acc += v[0];
+                    acc2 += v[1];
+                } else if (HAS_DW) acc += up[b];
+                else acc2 += up[b];
+            }
+        }
+    }
+    if (ok && col < ldz) {
+        if (HAS_DW) Cpart[(i64)rb * ldz + col] = acc;
+        if (NW) N2part[(i64)rb * ldz + col] = acc2;
+    }
+}
+
 // Both fixed-order reductions of a weighted T-row step in one launch (they were two launches of k_reduce), with the
 // correction above:  red[j] = sum_b Zpart[b][j] - tprow[j] sum_b Cpart[b][j] ,  red[ldz + j] = sum_b Z2part[b][j].
 // Cpart == NULL: no term pending.  Row-sharded runs all-reduce red afterwards: the correction is a sum over rows like z.
@@ -386,7 +477,7 @@ __global__ __launch_bounds__(256) void k_wmcorr(const SX* __restrict__ M, i64 ld
 // at the position of THIS step -- the T-row kernel that follows returns at once when it halts the run: one launch less per step.
 __device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int sweep, int pos, const KParams& p, DevState* st);
 __global__ __launch_bounds__(1024) void k_wreduce(const double* __restrict__ Zpart, const double* __restrict__ Z2part, i64 ldz,
-                                                  int nrb, const double* __restrict__ Cpart, int nrbc,
+                                                  int nrb, int nrb2, const double* __restrict__ Cpart, int nrbc,
                                                   const double* __restrict__ tprow, double* __restrict__ red,
                                                   const double* __restrict__ Gpart, int nwb, int k, int check_prev, int tprev,
                                                   int sweep, int pos, KParams p, DevState* st) {
@@ -421,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_wreduce(const double* __restrict__ Zpa
     };
     if (j < ldz) {      // ldz is even and j is even: the pair is inside the row
         sum2(Zpart, nrb, a);
-        sum2(Z2part, nrb, b);
+        sum2(Z2part, nrb2, b);      // the pass's row blocks, or the mask-only kernel's (k_wmcorr_cols<.., NW>)
         if (Cpart) sum2(Cpart, nrbc, cc);
     }
     __shared__ double sh2[3][32 * 33];
@@ -475,7 +566,7 @@ __device__ __forceinline__ void wcol_verdict(double a, double f, int tprev, int 
 // sums -- the same decision everywhere, nothing is updated when the step halts -- and leaves red = [a | nw] as k_reduce does.
 __global__ __launch_bounds__(128) void k_wtrow_small(const double* __restrict__ T, i64 ldt, int d, int t,
                                                      const double* __restrict__ Zpart, const double* __restrict__ Z2part,
-                                                     i64 ldz, int nrb, const double* __restrict__ Cpart, int nrbc,
+                                                     i64 ldz, int nrb, int nrb2, const double* __restrict__ Cpart, int nrbc,
                                                      const double* __restrict__ tprow,
                                                      const double* __restrict__ Gpart, int nwb, int k,
                                                      int check_prev, int tprev, int sweep, double* __restrict__ red,
@@ -501,7 +592,7 @@ __global__ __launch_bounds__(128) void k_wtrow_small(const double* __restrict__ 
     double x = 0.0, neg = 0.0;
     if (j < ldz) {
         double a = ordered_sum<8>(Zpart + j, ldz, 0, nrb, 1);
-        const double nw = ordered_sum<8>(Z2part + j, ldz, 0, nrb, 1);
+        const double nw = ordered_sum<8>(Z2part + j, ldz, 0, nrb2, 1);
         // the rank-one term the last W update left pending in E (k_wmcorr): a_j = z_j - t'_j c_j
         if (Cpart) a = fma(-tprow[j], ordered_sum<8>(Cpart + j, ldz, 0, nrbc, 1), a);
         red[j] = a;

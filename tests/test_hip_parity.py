@@ -367,6 +367,54 @@ def test_weighted_recsys_fixture(dtype):
         assert np.allclose(objs, g['c%d_obj' % ci], rtol=(1e-6 if dtype == np.float64 else 1e-4))
 
 
+@pytest.mark.parametrize('shape', [(700, 333, 6), (257, 1030, 5), (4133, 520, 4), (31, 7, 2), (9000, 64, 3)])
+def test_sparse_mask_correction_walks_set_bits_only(monkeypatch, shape):
+    """k_wmcorr_cols (round 4): below 12 % density the mask-only correction of the one-pass weighted step reads a second packed
+    copy of the mask with the rows in the bits and adds u[row] for the SET bits alone.  Same sums as the kernel that walks every
+    bit (RRI_WMCORR_COLS=0), other row-block partition: agreement to summation order, on ragged shapes (rows not a multiple of
+    32 or of a row block, columns not a multiple of 4 / 64 / 256), and against the oracle.  The same launch then takes the T-row
+    step's second column sum nw = (w^2)^T M as well and the read-modify-write pass leaves it out (RRI_WNW_MASK=0: it does not)."""
+    n, d, k = shape
+    X = planted_X(n, d, k, seed=n, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=1)
+    M = (np.random.RandomState(2).rand(n, d) < 0.06).astype(np.float64)
+    M[:, 0] = 1.0          # a full column and an empty one beside the ragged rest
+    M[:, d - 1] = 0.0
+    M[0, :] = 1.0          # every topic row stays determined
+    Xm = M * X
+    flags = dict(t_row_sum=1.0, reset_topic_method=None)
+    monkeypatch.setenv('RRI_ONCHIP', '0')
+    out = {}
+    # (set bits only, nw = (w^2)^T M from the same launch) | (set bits only, nw from the pass) | (every bit, nw from the pass)
+    for sw in (('1', '1'), ('1', '0'), ('0', '1')):
+        monkeypatch.setenv('RRI_WMCORR_COLS', sw[0])
+        monkeypatch.setenv('RRI_WNW_MASK', sw[1])
+        out[sw] = run_weighted(Xm, M, W0, T0, 3, np.float64, **flags)
+    b = out[('0', '1')]
+    for sw in (('1', '1'), ('1', '0')):
+        a = out[sw]
+        assert relfro(a[0], b[0]) < 1e-11 and relfro(a[1], b[1]) < 1e-11 and abs(a[2] - b[2]) <= 1e-11 * abs(b[2]), \
+            (sw, relfro(a[0], b[0]), relfro(a[1], b[1]))
+    a = out[('1', '1')]
+    ref = run_oracle(Xm, W0, T0, 3, W_mat=M, compute_obj_each_iter=True, **flags)
+    assert relfro(M * (a[0] @ a[1]), M * (ref['W'] @ ref['T'])) < 1e-8
+    assert abs(a[2] - ref['obj_history'][-1]) < 1e-8 * abs(a[2])
+    # fixed halves, penalties and fp32 storage through the same kernels
+    for kw, dt in ((dict(fix_W=True), np.float64), (dict(fix_T=True), np.float64), (dict(reg_w_l1=0.05, reg_t_l2=0.02), np.float32)):
+        def outcome(sw):
+            monkeypatch.setenv('RRI_WMCORR_COLS', sw)
+            try:
+                return run_weighted(stored(Xm, dt), M, W0, T0, 2, dt, **dict(flags, **kw))
+            except (AssertionError, ValueError) as exc:      # the reference's own stops (an emptied column on the 31 x 7 case)
+                return str(exc)
+        a, b = outcome('1'), outcome('0')
+        if isinstance(a, str) or isinstance(b, str):
+            assert a == b, (kw, a, b)
+            continue
+        tol = 1e-11 if dt == np.float64 else 1e-5
+        assert relfro(a[0], b[0]) < tol and relfro(a[1], b[1]) < tol, (kw, relfro(a[0], b[0]), relfro(a[1], b[1]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('store', [np.float32, np.float64])
 def test_objective_without_a_pass_over_X(store, monkeypatch):

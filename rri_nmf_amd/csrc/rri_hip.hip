@@ -140,6 +140,8 @@ struct rri_ctx {
     i64 ldb = 0;
     double* Qt = nullptr;     // X T^T (k x n), valid while T is fixed
     bool q_valid = false;
+    bool gfull_valid = false;   // Gfull = T T^T of the current T (k_wsweep_rows)
+    double *Gfull = nullptr, *Wsweep0 = nullptr, *wsum_part = nullptr, *wsums = nullptr;   // whole-sweep W half with T fixed: lazily allocated
     double *Y2part = nullptr, *Z2part = nullptr, *dtv = nullptr, *dwv = nullptr, *wold = nullptr, *zeros = nullptr;  // weighted
     i64 ldw = 0;     // row stride of the k-major W (>= n)
     int nsplit = 4;  // column slices of k_tgram
@@ -462,6 +464,7 @@ int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its o
 int g_onchip = 1;       // RRI_ONCHIP=0: never the register-resident persistent sweep (rri_onchip_kernels.hpp)
 int g_onchip_obj = 1;   // RRI_ONCHIP_OBJ=0: the persistent sweep does not leave the objective of its last sweep (rri_objective takes the Gram kernels)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
+int g_wsweep = 1;        // RRI_WSWEEP=0: runs with T fixed take the launch-per-topic W half (k_tgram, k_wcol, k_check_wcol per topic)
 int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
 int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
                              // interleaved up to 1024 workgroups (+2 % at 20000 x 5000; -1 % at C3, where it stays off)
@@ -1182,7 +1185,7 @@ void enqueue_T_half(rri_ctx* c, int sweep, int t, bool standalone) {
     }
     c->carry_valid = false;
     c->resid_valid = false;
-    c->q_valid = false;   // T changed
+    c->q_valid = false; c->gfull_valid = false;   // T changed
     c->xy_valid = false;  // a T row changed: complete again after the W half of topic k-1
     c->obj_track_valid = false;
 }
@@ -1498,6 +1501,62 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     c->carry_topic = tn;
 }
 
+// ---- T fixed: the W half of all topics of a sweep as one launch (k_wsweep_rows) ---------------------------------------
+bool wsweep_ok(const rri_ctx* c) {
+    return g_wsweep && c->prm.fix_T && !c->prm.fix_W && !c->weighted && !c->sparse && c->k >= 1 &&
+           wsweep_lds_bytes(c->k) <= 150 * 1024;
+}
+// topics [t0, k) of sweep `sweep`; false: a buffer could not be had (the caller takes the launch-per-topic schedule)
+bool enqueue_wsweep(rri_ctx* c, int sweep, int t0) {
+    const int k = c->k;
+    const size_t f8 = sizeof(double);
+    if (!c->Gfull && hipMalloc((void**)&c->Gfull, (size_t)k * k * f8) != hipSuccess) { c->Gfull = nullptr; (void)hipGetLastError(); return false; }
+    if (!c->Wsweep0 && hipMalloc((void**)&c->Wsweep0, (size_t)k * c->ldw * f8) != hipSuccess) { c->Wsweep0 = nullptr; (void)hipGetLastError(); return false; }
+    if (!c->wsum_part && hipMalloc((void**)&c->wsum_part, (size_t)k * c->nwb * f8) != hipSuccess) { c->wsum_part = nullptr; (void)hipGetLastError(); return false; }
+    if (!c->wsums && hipMalloc((void**)&c->wsums, (size_t)k * f8) != hipSuccess) { c->wsums = nullptr; (void)hipGetLastError(); return false; }
+    static bool attr_set[64] = {};
+    const int dv = c->device & 63;
+    if (!attr_set[dv]) {
+        if (hipFuncSetAttribute((const void*)k_wsweep_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+        attr_set[dv] = true;
+    }
+    if (c->pending_wcheck) {     // (a column check left by steps before T was fixed)
+        wcheck_now(c, c->pending_wcheck_topic, sweep, t0);
+        c->pending_wcheck = false;
+    }
+    if (!c->q_valid) {           // X T^T: once per T, reused by every topic and every sweep
+        DISPATCH(c, L::xtt(c));
+        c->q_valid = true;
+    }
+    if (!c->gfull_valid) {
+        hipLaunchKernelGGL(k_gram, dim3(k, k), dim3(256), 0, c->stream, (const double*)c->T, c->LD, c->d, k, c->Gfull);
+        c->gfull_valid = true;
+    }
+    {
+        TimedScope ts(c, 1);
+        hipLaunchKernelGGL(k_wsweep_rows, dim3(c->nwb), dim3(64), wsweep_lds_bytes(k), c->stream, c->W, c->Wsweep0, c->ldw, (int)c->n, k,
+                           t0, (const double*)c->Qt, (const double*)c->Gfull, c->wsum_part, c->nwb, c->XYpart, (i64)c->xy_stride,
+                           kparams(c), (const DevState*)c->st);
+        if (!c->comm)
+            hipLaunchKernelGGL(k_wsweep_verdict, dim3(1), dim3(1024), 0, c->stream, (const double*)c->wsum_part, c->nwb, c->wsums,
+                               (const double*)c->Gfull, k, t0, sweep, 3, kparams(c), c->st);
+        else {      // row-sharded: the column sums of all k topics in ONE all-reduce (the launch-per-topic schedule takes k)
+            hipLaunchKernelGGL(k_wsweep_verdict, dim3(1), dim3(1024), 0, c->stream, (const double*)c->wsum_part, c->nwb, c->wsums,
+                               (const double*)c->Gfull, k, t0, sweep, 1, kparams(c), c->st);
+            comm_allreduce(c, c->wsums, k);
+            hipLaunchKernelGGL(k_wsweep_verdict, dim3(1), dim3(1024), 0, c->stream, (const double*)c->wsum_part, c->nwb, c->wsums,
+                               (const double*)c->Gfull, k, t0, sweep, 2, kparams(c), c->st);
+        }
+        hipLaunchKernelGGL(k_wsweep_repair, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->W, (const double*)c->Wsweep0,
+                           c->ldw, (int)c->n, k, (const DevState*)c->st);
+    }
+    for (int t = t0; t < k; ++t) LK::note_xy(c, t, c->nwb * WCOL_TILES);
+    c->skip_row_finish = false;
+    c->carry_valid = false;
+    c->resid_valid = false;
+    return true;
+}
+
 // sweeps [cur .. s_end) of the current call
 void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
     const int k = c->k;
@@ -1536,6 +1595,7 @@ void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
     for (int s = cur.sweep; s < s_end; ++s) {
         const int t0 = (s == cur.sweep) ? cur.topic : 0;
         const int sa = s;
+        if (wsweep_ok(c) && enqueue_wsweep(c, sa, t0)) continue;      // T fixed: the W half of every topic in one launch
         for (int t = t0; t < k; ++t) {
             const int ph = (s == cur.sweep && t == cur.topic) ? cur.phase : 0;
             if (!c->prm.fix_T && ph == 0) enqueue_T_half(c, sa, t, c->prm.fix_W != 0);
@@ -1746,7 +1806,7 @@ bool enqueue_onchip(rri_ctx* c, Cursor cur) {
     const bool whole_last = c->run_total - 1 > cur.sweep || (cur.topic == 0 && cur.phase == 0);
     c->carry_valid = false; c->carry_topic = -1;
     c->pending_wcheck = false;
-    c->resid_valid = false; c->q_valid = false;
+    c->resid_valid = false; c->q_valid = false; c->gfull_valid = false;
     c->skip_row_finish = false;
     c->xy_run = whole_last ? k : -1;
     c->xy_rows = g.G;
@@ -1888,6 +1948,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     // the switches are per process and read again by every rri_create: an unset variable means the default, not "what
     // the last handle was created with"
     g_pass_unroll = 8; g_pass_unroll_upd = 16; g_pass_nt = -1; g_pass_rs = 1; g_obj_direct = 0; g_pass_interleave = -1;
+    g_wsweep = 1;
+    if (const char* e = getenv("RRI_WSWEEP")) g_wsweep = atoi(e) != 0;
     g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_onchip_obj = 1; g_wpass_il = -1;
     g_wpass_uc = 8;
     g_wpass_one = 1;
@@ -2097,7 +2159,7 @@ rri_status rri_destroy(rri_ctx* c) {
                     (void*)c->tpart, (void*)c->tpart_idx, (void*)c->rowobj, (void*)c->rowpos, (void*)c->normpart,
                     (void*)c->dtmp, (void*)c->itmp, (void*)c->resetT, (void*)c->resetW, (void*)c->st, (void*)c->Y2part,
                     (void*)c->Z2part, (void*)c->Mbits, (void*)c->Qt, (void*)c->dtv, (void*)c->dwv, (void*)c->wold, (void*)c->zeros,
-                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->Cpart, (void*)c->N2part, (void*)c->Mcols, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
+                    (void*)c->XYpart, (void*)c->objbuf, (void*)c->told, (void*)c->Cpart, (void*)c->N2part, (void*)c->Mcols, (void*)c->Gfull, (void*)c->Wsweep0, (void*)c->wsum_part, (void*)c->wsums, (void*)c->ctail, (void*)c->cand, (void*)c->mkZ, (void*)c->mkG, (void*)c->mkP, (void*)c->mkX, (void*)c->mkT, (void*)c->objE, (void*)c->objhist, (void*)c->objdec, (void*)c->mkbar, (void*)c->Wsafe, (void*)c->Tsafe, (void*)c->sp_rowptr, (void*)c->sp_col, c->sp_x, c->sp_e, (void*)c->sp_Tt,
                     (void*)c->sp[0].segptr, (void*)c->sp[0].idx, c->sp[0].val, (void*)c->sp[0].perm, (void*)c->sp[0].work,
                     (void*)c->sp[1].segptr, (void*)c->sp[1].idx, c->sp[1].val, (void*)c->sp[1].perm, (void*)c->sp[1].work};
     for (void* b : bufs)
@@ -2124,7 +2186,7 @@ rri_status rri_upload_X(rri_ctx* c, const void* host, int64_t ld, int32_t host_d
     }
     c->ldx = c->LD;
     rri_status s = to_device(c, host, ld, host_dtype, c->X, c->ldx, c->n, c->d, c->dtype);
-    if (s == RRI_OK) { c->have_X = true; invalidate(c); c->q_valid = false; c->x_sq_valid = false; }
+    if (s == RRI_OK) { c->have_X = true; invalidate(c); c->q_valid = false; c->gfull_valid = false; c->x_sq_valid = false; }
     return s;
 }
 
@@ -2206,7 +2268,7 @@ rri_status rri_upload_X_csr(rri_ctx* c, const int64_t* indptr, const int32_t* in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_X = true;
     invalidate(c);
-    c->q_valid = false;
+    c->q_valid = false; c->gfull_valid = false;
     c->x_sq_valid = false;
     return RRI_OK;
 }
@@ -2394,7 +2456,7 @@ rri_status rri_bind_X_device(rri_ctx* c, const void* dev, int64_t ld) {
     c->ldx = ld;
     c->have_X = true;
     invalidate(c);
-    c->q_valid = false;
+    c->q_valid = false; c->gfull_valid = false;
     c->x_sq_valid = false;
     return RRI_OK;
 }
@@ -2431,7 +2493,7 @@ rri_status rri_set_T(rri_ctx* c, const void* host, int64_t ld, int32_t host_dtyp
     CHECK_CTX(c);
     HIPCHK(c, hipSetDevice(c->device));
     rri_status s = to_device(c, host, ld, host_dtype, c->T, c->LD, c->k, c->d, RRI_F64);
-    if (s == RRI_OK) { c->have_T = true; invalidate(c); c->q_valid = false; }
+    if (s == RRI_OK) { c->have_T = true; invalidate(c); c->q_valid = false; c->gfull_valid = false; }
     return s;
 }
 rri_status rri_get_W(rri_ctx* c, void* host, int64_t ld, int32_t host_dtype) {
@@ -2596,7 +2658,7 @@ rri_status rri_pending_event(rri_ctx* c, rri_event* ev) {
 }
 
 static void event_resolved(rri_ctx* c) {
-    c->q_valid = false;   // a reset rewrites T[t,:] even when T is otherwise fixed (nmf.py:808,814)
+    c->q_valid = false; c->gfull_valid = false;   // a reset rewrites T[t,:] even when T is otherwise fixed (nmf.py:808,814)
     if (c->pending.kind == RRI_EVENT_RESET_T) c->skip_row_finish = true;
     c->pending.kind = RRI_EVENT_NONE;
     if (c->prm.resets_left > 0) c->prm.resets_left -= 1;
@@ -2962,7 +3024,7 @@ rri_status rri_rollback(rri_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->T, c->Tprev, (size_t)c->k * c->LD * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate(c);
-    c->q_valid = false;
+    c->q_valid = false; c->gfull_valid = false;
     c->pending_wcheck = false;
     return RRI_OK;
 }
@@ -3264,7 +3326,7 @@ rri_status rri_scale_X(rri_ctx* c, const double* col_scale, int32_t normalize_ro
                                    (const double*)invdev));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate(c);
-    c->q_valid = false;
+    c->q_valid = false; c->gfull_valid = false;
     c->x_sq_valid = false;
     return RRI_OK;
 }
@@ -3368,7 +3430,7 @@ rri_status rri_topic_finish(rri_ctx* c, int32_t t) {
     LK::trow(c, t, chk, c->pending_wcheck_topic, 0, c->prm.fix_W != 0);
     c->pending_wcheck = false;
     c->carry_valid = false;
-    c->q_valid = false;
+    c->q_valid = false; c->gfull_valid = false;
     c->xy_valid = false;
     c->obj_track_valid = false;
     if (c->prm.fix_W) {

@@ -43,7 +43,7 @@ struct DevState {
     int halt_pos;
     int tmode;       // qf_min branch of the current T row: 0 c>0, 1 c<=0 bounds, 2 c<=0 one-hot
     int proj_iters;  // Michelot iterations of the last projection (diagnostic)
-    int pad0;
+    int pad0;        // k_wsweep_verdict: first column k_wsweep_repair restores after a reset event (0: none); cleared with halt
     int pad1;
     double nt1;      // 1-norm of the unprojected T-row solution (qf_min's nx, nmf.py:447)
     double nt;       // ||T[t,:]||^2
@@ -684,6 +684,171 @@ __global__ __launch_bounds__(256) void k_wcol(double* __restrict__ Wt, i64 ldw, 
     __syncthreads();
     double* gp = Gpart + (i64)blockIdx.x * (k + 2);
     for (int l = tid; l < k + 2; l += 256) gp[l] = gsh[l];
+}
+
+// =========================================================================================
+// k_wsweep_rows: the W half of EVERY topic of a sweep in one launch, for runs with T fixed (the fold-in of new rows,
+// sklearn_interface.py:327-333; the w_row refit, nmf.py:531-539).  With T fixed the update of W[i, t] (nmf.py:464-469, 728-734)
+//     numer = (X T^T)[i, t] - sum_{l != t} W[i, l] (T T^T)[l, t] - reg_w_l1 ,   denom = ||T[t,:]||^2 + reg_w_l2
+// involves row i of W alone: Q = X T^T (k_xtt) and G = T T^T (k_gram) are constants of the run, taken once per T, and a lane
+// walks the k topics of its row with the row and G in LDS -- k^2 fused multiply-adds per row, no pass over X, one launch where
+// the launch-per-topic schedule takes three per topic (k_tgram, k_wcol, k_check_wcol).  Same branches of qf_min as k_wcol.
+// What couples the rows is the column check after every update (nmf.py:471-476, 793-816): the kernel leaves the column sums as
+// one partial per workgroup and topic, k_wsweep_verdict takes the verdicts in topic order after the launch, and when a
+// column asks for a reset at topic t* (rare), k_wsweep_repair puts the columns after t* back to what they were before the
+// sweep (Wprev, written here on the way in): the state in which the launch-per-topic schedule halts.  The cross terms
+// <w_t, X t_t> of the objective go to xyp as k_wcol leaves them (one partial per 64 rows).
+// =========================================================================================
+// Four topics at a time: the terms of the four dots that come from columns OUTSIDE the block share one read of W[i, l] and two
+// 16-byte reads of G[l, t .. t+3] (three LDS reads for four multiply-adds where a topic on its own takes eight); the six terms
+// inside the block follow in registers, topic by topic.  (X T^T)[i, t .. t+3] of the NEXT block is requested before this one is
+// worked on.  A dot is therefore summed as (columns before the block, ascending) + (columns after it) + (the block's others).
+__host__ __device__ constexpr int wsweep_kp(int k) { return (k + 3) & ~3; }
+__host__ __device__ constexpr size_t wsweep_lds_bytes(int k) { return ((size_t)k * wsweep_kp(k) + 64 * (size_t)k) * sizeof(double); }
+
+__global__ __launch_bounds__(64) void k_wsweep_rows(double* __restrict__ Wt, double* __restrict__ Wprev, i64 ldw, int n, int k,
+                                                    int t0, const double* __restrict__ Qt, const double* __restrict__ G,
+                                                    double* __restrict__ colsum, int nwb, double* __restrict__ xyp,
+                                                    i64 xy_stride, KParams p, const DevState* __restrict__ st) {
+    if (st->halt) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int kp = wsweep_kp(k);
+    double* gsh = reinterpret_cast<double*>(smem);   // [k][kp]  (symmetric to the bit: k_gram writes both halves from one sum)
+    double* wsh = gsh + (size_t)k * kp;              // [k][64] the rows' entries of W, current
+    const int lane = threadIdx.x;
+    const i64 i = (i64)blockIdx.x * 64 + lane;
+    const bool valid = i < n;
+    for (int q = lane; q < k * kp; q += 64) {
+        const int l = q / kp, c = q - l * kp;
+        gsh[q] = c < k ? G[(i64)l * k + c] : 0.0;
+    }
+    constexpr int CH = 8;
+    for (int l0 = 0; l0 < k; l0 += CH) {
+        double wv[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) wv[q] = (l0 + q < k && valid) ? Wt[(i64)(l0 + q) * ldw + i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int l = l0 + q;
+            if (l < k) {
+                wsh[l * 64 + lane] = wv[q];
+                if (valid) Wprev[(i64)l * ldw + i] = wv[q];
+            }
+        }
+    }
+    const int tb0 = t0 & ~3;
+    double yv[4], yn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yv[j] = (tb0 + j < k && valid) ? Qt[(i64)(tb0 + j) * ldw + i] : 0.0;
+    __syncthreads();
+    for (int tb = tb0; tb < k; tb += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yn[j] = (tb + 4 + j < k && valid) ? Qt[(i64)(tb + 4 + j) * ldw + i] : 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        auto outside = [&](int la, int lb) {
+#pragma unroll 4
+            for (int l = la; l < lb; ++l) {
+                const double wl = wsh[l * 64 + lane];
+                const f64x2 g01 = *reinterpret_cast<const f64x2*>(gsh + (size_t)l * kp + tb);
+                const f64x2 g23 = *reinterpret_cast<const f64x2*>(gsh + (size_t)l * kp + tb + 2);
+                acc[0] = fma(wl, g01[0], acc[0]);
+                acc[1] = fma(wl, g01[1], acc[1]);
+                acc[2] = fma(wl, g23[0], acc[2]);
+                acc[3] = fma(wl, g23[1], acc[3]);
+            }
+        };
+        outside(0, tb);
+        outside(min(tb + 4, k), k);
+        double wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = tb + j < k ? wsh[(tb + j) * 64 + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = tb + j;
+            if (t >= k || t < t0) continue;           // (wave-uniform)
+            const double* gr = gsh + (size_t)t * kp;
+            const double cden = gr[t] + p.reg_w_l2;   // denom = nt + reg_w_l2 (nmf.py:465)
+            int mode = 0;
+            if (!(cden > 0.0)) {                      // scalar c <= 0 with s = None (optimization.py:60-67): entries jump to ub, or
+                if (p.has_wrs && p.w_row_sum != 0.0) mode = 1;
+                else continue;                        // unbounded -- k_wsweep_verdict reports it at this topic; the column stays
+            }
+            double dot = acc[j];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2)
+                if (j2 != j && tb + j2 < k) dot = fma(wb[j2], gr[tb + j2], dot);     // Tt[t] = 0 (nmf.py:732): j2 == j left out
+            const double y = yv[j];
+            const double numer = (y - dot) - p.reg_w_l1;
+            double wnew = 0.0;
+            if (valid) {
+                if (mode == 0) wnew = fmax(numer, 0.0) / (cden + p.eps);
+                else wnew = (-numer + cden < 0.0) ? p.w_row_sum : 0.0;
+                Wt[(i64)t * ldw + i] = wnew;
+            }
+            wb[j] = wnew;
+            wsh[t * 64 + lane] = wnew;
+            const double sw = wave_sum<double>(wnew);
+            const double xy = wave_sum<double>(wnew * y);
+            if (lane == 0) {
+                colsum[(i64)t * nwb + blockIdx.x] = sw;
+                xyp[(i64)t * xy_stride + blockIdx.x] = xy;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = yn[j];
+    }
+}
+
+// the column checks of a k_wsweep_rows launch, in topic order: stage bit 0 -- sums[t] = sum over the workgroups' partials (a
+// wave per topic, fixed order); bit 1 -- the verdicts on sums (row-sharded runs all-reduce sums in between), those of k_wcol
+// (unbounded: a non-positive denominator with no bound to jump to) and k_check_wcol, halting at the FIRST topic that fails
+// with the position the launch-per-topic schedule reports.  A reset event also leaves pad0 = t* + 1 for k_wsweep_repair.
+__global__ __launch_bounds__(1024) void k_wsweep_verdict(const double* __restrict__ colsum, int nwb, double* __restrict__ sums,
+                                                         const double* __restrict__ G, int k, int t0, int sweep, int stage,
+                                                         KParams p, DevState* st) {
+    if (st->halt) return;
+    __shared__ double ssum[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (stage & 1) {
+        for (int t = t0 + wave; t < k; t += 16) {
+            double a = ordered_sum<8>(colsum + (i64)t * nwb, 1, lane, nwb, 64);
+            a = wave_sum<double>(a);
+            if (lane == 0) { sums[t] = a; ssum[t] = a; }
+        }
+    }
+    if (!(stage & 2)) return;
+    if (!(stage & 1))
+        for (int t = t0 + (int)threadIdx.x; t < k; t += 1024) ssum[t] = sums[t];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int t = t0; t < k; ++t) {
+        const double cden = G[(i64)t * k + t] + p.reg_w_l2;
+        if (!(cden > 0.0) && !(p.has_wrs && p.w_row_sum != 0.0)) {
+            st->halt = HALT_ERR_UNBOUNDED; st->halt_topic = t; st->halt_sweep = sweep; st->halt_pos = t;
+            return;
+        }
+        const double a = ssum[t];
+        const bool ev = (a <= 1e-10) && p.reset_method != RESET_NONE && p.resets_left > 0;
+        const bool err = !ev && !(a > 0.0);
+        if (ev || err) {
+            st->halt = ev ? HALT_EVENT_RESET_W : HALT_ERR_W_COL_ZERO;
+            st->halt_topic = t;
+            st->halt_sweep = t + 1 == k ? sweep + 1 : sweep;     // position of the NEXT step, where a resumed run continues
+            st->halt_pos = t + 1 == k ? 0 : t + 1;
+            if (ev) st->pad0 = t + 1;
+            return;
+        }
+    }
+}
+
+// after a reset event of k_wsweep_verdict at topic t*: columns t* + 1 .. k - 1 of W as they were before the sweep
+__global__ __launch_bounds__(256) void k_wsweep_repair(double* __restrict__ Wt, const double* __restrict__ Wprev, i64 ldw, int n,
+                                                       int k, const DevState* __restrict__ st) {
+    const int from = st->pad0;
+    if (from <= 0 || st->halt != HALT_EVENT_RESET_W) return;
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int l = from; l < k; ++l) Wt[(i64)l * ldw + i] = Wprev[(i64)l * ldw + i];
 }
 
 // =========================================================================================

@@ -143,6 +143,78 @@ def test_regularised_and_fixed_halves(dtype):
     assert relfro(W, ref['W']) < TOL[dtype] and relfro(T, ref['T']) < TOL[dtype]
 
 
+@pytest.mark.parametrize('shape', [(700, 333, 6), (65, 40, 1), (5003, 257, 64), (1200, 90, 80), (64, 30, 3)])
+def test_fixed_T_whole_sweep_launch_matches_the_launch_per_topic_schedule(monkeypatch, shape):
+    """k_wsweep_rows (round 4): with T fixed the W half of every topic of a sweep is ONE launch -- row i of W needs only its own
+    entries, (X T^T)[i, :] and T T^T -- and the column checks are taken in topic order afterwards (k_wsweep_verdict).  Against
+    the launch-per-topic schedule (RRI_WSWEEP=0: k_tgram, k_wcol, k_check_wcol per topic) and the oracle: plain, penalties, the
+    bound w_row_sum, the non-positive-denominator branch of qf_min, both storage types, ragged row counts (not a multiple of 64),
+    k = 1 and k beyond 64; sweeps in one call and call by call."""
+    n, d, k = shape
+    X = planted_X(n, d, max(k, 2), seed=n + k, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=5)
+    monkeypatch.setenv('RRI_ONCHIP', '0')
+
+    def run(sw, store, sweeps=3, **flags):
+        monkeypatch.setenv('RRI_WSWEEP', sw)
+        # (nmf()'s final projection of the rows of W when w_row_sum is given, nmf.py:519-529)
+        return run_engine(X, W0, T0, sweeps, store, final_proj=flags.get('w_row_sum'), fix_T=True, **flags)
+
+    for store in (np.float64, np.float32):
+        for flags in (dict(), dict(reg_w_l1=0.02, reg_w_l2=0.05), dict(t_row_sum=1.0, w_row_sum=1.0),
+                      dict(w_row_sum=0.7, reg_w_l2=-1e9)):       # the last: denom <= 0, entries jump to the bound or to 0
+            a, b = run('1', store, **flags), run('0', store, **flags)
+            # T: untouched -- but for the row a reset rewrites from the residual (k = 80 empties a column of W: nmf.py:804-810)
+            assert relfro(a[1], b[1]) < 1e-12 and relfro(a[0], b[0]) < 1e-12, (store, flags, relfro(a[0], b[0]), relfro(a[1], b[1]))
+            ref = run_oracle(stored(X, store), W0, T0, 3, fix_T=True, **flags)
+            assert relfro(a[0], ref['W']) < TOL[store], (store, flags, relfro(a[0], ref['W']))
+    # call by call == one call; the objective after the sweeps comes from the cross terms the launch left (no pass over X)
+    with engine(n, d, k, dtype=np.float64) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params(fix_T=True)
+        for _ in range(3):
+            e.sweep(1)
+        W1, o1 = e.get_W(), e.objective()
+    with engine(n, d, k, dtype=np.float64) as e:
+        e.upload_X(X); e.set_W(W0); e.set_T(T0); e.set_params(fix_T=True)
+        e.sweep(3)
+        W3, T3, o3 = e.get_W(), e.get_T(), e.objective()
+    assert np.array_equal(W1, W3) and o1 == o3
+    # (T3, not T0: at k = 80 a column of W empties and the default reset rewrites its row of T, fixed or not -- nmf.py:804-810)
+    assert abs(o3 - 0.5 * np.linalg.norm(X - W3 @ T3) ** 2) <= 1e-9 * abs(o3)
+
+
+def test_fixed_T_whole_sweep_launch_halts_where_the_reference_does(monkeypatch):
+    """A column of W that the update empties (nmf.py:471-476, 793-816) in the middle of a whole-sweep launch: with a reset method
+    the run pauses at that topic with the later columns as they were before the sweep (k_wsweep_repair), the reset is drawn and
+    the sweep goes on from the next topic -- the same W, T and reset count as the launch-per-topic schedule and the oracle;
+    without one, the reference's assertion."""
+    n, d, k = 900, 120, 5
+    X = planted_X(n, d, k, seed=3, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=4)
+    X[:, :10] = 0.0                      # topic 2 lives on columns where X is empty: its column of W goes to zero
+    T0[2, :] = 0.0
+    T0[2, :10] = 1.0
+    monkeypatch.setenv('RRI_ONCHIP', '0')
+    out = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('RRI_WSWEEP', sw)
+        with engine(n, d, k, dtype=np.float64) as e:
+            e.upload_X(X); e.set_W(W0); e.set_T(T0)
+            e.set_params(fix_T=True, reset_topic_method='random', fix_reset_seed=True, n_resets=2)
+            e.sweep(3)
+            out[sw] = (e.get_W(), e.get_T(), e.n_resets_used, list(e.reset_log))
+        with engine(n, d, k, dtype=np.float64) as e:
+            e.upload_X(X); e.set_W(W0); e.set_T(T0)
+            e.set_params(fix_T=True, reset_topic_method=None)
+            with pytest.raises(AssertionError, match='sums to 0'):
+                e.sweep(2)
+    a, b = out['1'], out['0']
+    assert a[2] == b[2] >= 1 and a[3] == b[3], (a[2], b[2], a[3], b[3])
+    assert relfro(a[0], b[0]) < 1e-12 and relfro(a[1], b[1]) < 1e-12, (relfro(a[0], b[0]), relfro(a[1], b[1]))
+    ref = run_oracle(X, W0, T0, 3, fix_T=True, reset_topic_method='random', fix_reset_seed=True, n_resets=2)
+    assert relfro(a[0], ref['W']) < 2e-9 and relfro(a[1], ref['T']) < 2e-9, (relfro(a[0], ref['W']), relfro(a[1], ref['T']))
+
+
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_text_fixture_topic_assignments_are_exact(dtype):
     """BASELINE north_star: bit-exact argmax topic assignments on the reference's fixture."""

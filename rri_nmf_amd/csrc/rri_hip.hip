@@ -464,6 +464,7 @@ int g_side_jobs = 1;    // RRI_SIDE_JOBS=0: every small job as a launch of its o
 int g_onchip = 1;       // RRI_ONCHIP=0: never the register-resident persistent sweep (rri_onchip_kernels.hpp)
 int g_onchip_obj = 1;   // RRI_ONCHIP_OBJ=0: the persistent sweep does not leave the objective of its last sweep (rri_objective takes the Gram kernels)
 int g_resid_mfma = 1;   // RRI_RESID_MFMA=0: the residual on the vector ALU for every k
+int g_resid_split = 0;   // RRI_RESID_SPLIT=n: column ranges per row block of the residual rebuild (0: chosen from the grid)
 int g_wsweep = 1;        // RRI_WSWEEP=0: runs with T fixed take the launch-per-topic W half (k_tgram, k_wcol, k_check_wcol per topic)
 int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
 int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
@@ -851,12 +852,22 @@ struct LaunchX {
         const unsigned nb = (unsigned)((c->n + 63) / 64);
         if (c->k <= 64 && g_resid_mfma) {   // the k-panel product on the matrix cores
             const int ks = c->k <= 16 ? 4 : c->k <= 32 ? 8 : c->k <= 48 ? 12 : c->k <= 52 ? 13 : 16;
-            const size_t shm = 2 * (size_t)(4 * ks) * 64 * sizeof(double);
+            const size_t shm = 2 * (size_t)(4 * ks) * RESID_TS * sizeof(double);
             const bool sums = rowobj || rowpos;      // a plain rebuild wants neither: its epilogue is convert, subtract, store
+            // column ranges per row block (the rebuild without row sums): ~12 rounds of the chip's 2 workgroups per CU or more, so
+            // that the last, partly filled round costs a twelfth and not a quarter (RRI_RESID_SPLIT=1: one range)
+            int nsplit = 1;
+            if (!sums && write_e) {
+                const i64 per_round = 2 * (i64)std::max(c->n_cu, 1);
+                nsplit = (int)std::min<i64>((c->d + 63) / 64, std::max<i64>(1, (12 * per_round + nb - 1) / nb));
+                if (g_resid_split > 0) nsplit = (int)std::min<i64>((c->d + 63) / 64, g_resid_split);
+            }
+            const int dchunk = (int)round_up((c->d + nsplit - 1) / nsplit, 64);
+            const unsigned ny = (unsigned)((c->d + dchunk - 1) / dchunk);
 #define RRI_RESID_M2(MK, WE, KS_, SM)                                                                                \
-    hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4, SM>), dim3(nb), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
+    hipLaunchKernelGGL((k_resid_mfma<SX, MK, WE, KS_, 4, SM>), dim3(nb, (SM) ? 1u : ny), dim3(256), shm, c->stream, (const SX*)c->X, c->ldx, \
                        (const SX*)c->M, c->ldm, (const unsigned*)c->Mbits, c->ldb, (const double*)c->W, c->ldw,      \
-                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD)
+                       (const double*)c->T, c->LD, (int)c->n, (int)c->d, c->k, rowobj, rowpos, (SX*)c->E, c->LD, (SM) ? (int)round_up(c->d, 64) : dchunk)
 // a residual written without its row sums (the per-sweep rebuild of the explicit-residual schedule) skips them; !(WE)
 // keeps the first branch from instantiating a kernel that no WRITE_E = false caller can reach
 #define RRI_RESID_M(MK, WE, KS_)                           \
@@ -1949,6 +1960,8 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     // the last handle was created with"
     g_pass_unroll = 8; g_pass_unroll_upd = 16; g_pass_nt = -1; g_pass_rs = 1; g_obj_direct = 0; g_pass_interleave = -1;
     g_wsweep = 1;
+    g_resid_split = 0;
+    if (const char* e = getenv("RRI_RESID_SPLIT")) g_resid_split = std::max(0, atoi(e));
     if (const char* e = getenv("RRI_WSWEEP")) g_wsweep = atoi(e) != 0;
     g_trow_small = 1; g_resid_mfma = 1; g_side_jobs = 1; g_onchip = 1; g_onchip_obj = 1; g_wpass_il = -1;
     g_wpass_uc = 8;

@@ -1500,18 +1500,23 @@ __global__ __launch_bounds__(256) void k_resid(const SX* __restrict__ X, i64 ldx
 // read is 16 consecutive doubles: no bank conflicts.
 // =========================================================================================
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int RESID_TS = 64;   // row stride of k_resid_mfma's T tile in LDS, in doubles (80 -- the two k-rows a half-wave reads then lie
+                               // 32 banks apart instead of on the same banks -- measured the same: 2.81 ms at BASELINE config 5)
 
 // SUMS = false (a rebuild of the stored residual that wants neither row sums): the epilogue is convert, subtract, store.
 template <typename SX, bool MASKED, bool WRITE_E, int KS, int WAVES, bool SUMS = true>   // KS = k-steps of 4 (4, 8, 12, 13 or 16): k <= 4 KS
-__global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void k_resid_mfma(const SX* __restrict__ X, i64 ldx, const SX* __restrict__ M,
                                                     i64 ldm, const unsigned* __restrict__ Mb, i64 ldb,
                                                     const double* __restrict__ Wt, i64 ldw,
                                                     const double* __restrict__ T, i64 ldt, int n, int d, int k,
                                                     double* __restrict__ rowobj, double* __restrict__ rowpos,
-                                                    SX* __restrict__ E, i64 lde) {
+                                                    SX* __restrict__ E, i64 lde, int dchunk) {
+    // blockIdx.y: the column range [y dchunk, (y+1) dchunk) of the row block (dchunk a multiple of 64; the builds that take row
+    // sums run with one range).  A row block over ALL columns is a long workgroup, and 1563 of them on 256 CUs x 2 are 3.05
+    // rounds: the last 26 ran a fourth round on an empty chip.
     constexpr int kp = 4 * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* tsh = reinterpret_cast<double*>(smem);   // [2][kp][64]
+    double* tsh = reinterpret_cast<double*>(smem);   // [2][kp][RESID_TS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 row0 = (i64)blockIdx.x * (16 * WAVES) + wave * 16;
     const int lr = lane & 15, lk = lane >> 4;
@@ -1540,7 +1545,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
     auto park = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NST; ++i)
-            if (tr + WAVES * i < kp) tsh[((size_t)buf * kp + tr + WAVES * i) * 64 + slot] = stage[i];
+            if (tr + WAVES * i < kp) tsh[((size_t)buf * kp + tr + WAVES * i) * RESID_TS + slot] = stage[i];
     };
     // X: rows row0 + lk + 4r, columns c0 + 4 lr .. + 3 (a 16-byte vector when the storage type is fp32 and the
     // columns are all there; elementwise at the ragged edge and for fp64 storage)
@@ -1563,38 +1568,88 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
             }
         }
     };
+    // the lane's nibble rows of the bit-packed mask, requested with the X tile of the same step (round 4: loaded where they
+    // were used, each of the four words was waited for on its own -- s_waitcnt vmcnt(0) four times per step and wave, with the
+    // next step's T and X tiles in the same queue: the matrix cores were busy 38 % of the rebuild, SQ_VALU_MFMA_BUSY_CYCLES)
+    unsigned mq[4] = {0xFu, 0xFu, 0xFu, 0xFu}, mn[4] = {0xFu, 0xFu, 0xFu, 0xFu};
+    auto fetch_m = [&](i64 c0, unsigned (&dst)[4]) {
+        if (!(MASKED && Mb)) return;
+        const i64 j = c0 + 4 * lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const i64 i = row0 + lk + 4 * r;
+            dst[r] = (i < n && j < d) ? Mb[(i >> 3) * ldb + (j >> 2)] : 0u;      // the raw word: shifted where it is used (a
+                                                                                   // shift here is a wait for the load here)
+        }
+    };
     double so[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
-    fetch(0);
-    fetch_x(0, xq);
+    const i64 cb = (i64)blockIdx.y * dchunk;
+    const i64 ce = cb + dchunk < (i64)d ? cb + dchunk : (i64)d;
+    fetch(cb);
+    fetch_x(cb, xq);
+    fetch_m(cb, mq);
     park(0);
     __syncthreads();
     int buf = 0;
-    for (i64 c0 = 0; c0 < d; c0 += 64, buf ^= 1) {
-        const bool more = c0 + 64 < d;
+    for (i64 c0 = cb; c0 < ce; c0 += 64, buf ^= 1) {
+        const bool more = c0 + 64 < ce;
         if (more) {                                  // the next T tile AND the next X tile: in flight during the MFMAs
             fetch(c0 + 64);                          // and the epilogue below (round 1 asked for X after the epilogue and
             fetch_x(c0 + 64, xn);                    // then waited for it -- vmcnt(0) before the park -- once per step)
+            fetch_m(c0 + 64, mn);
         }
         f64x4 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
-        const double* tb = tsh + (size_t)buf * kp * 64;
+        const double* tb = tsh + (size_t)buf * kp * RESID_TS;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double b = tb[(4 * s + lk) * 64 + 16 * c + lr];
+                const double b = tb[(4 * s + lk) * RESID_TS + 16 * c + lr];
                 acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], b, acc[c], 0, 0, 0);
             }
         }
+        // the next T tile goes to LDS BEFORE the epilogue's stores are issued: the wait for its loads is a wait for everything this
+        // wave has in the vector-memory queue, and after the epilogue that includes the four 16-byte stores of E -- their
+        // acknowledgement was waited for in every step (round 4, from the ISA: s_waitcnt vmcnt(0) between the last store and the
+        // first ds_write).  Here the stores of a step have the matrix-core phase of the next one to land.
+        if (more) park(buf ^ 1);
         // epilogue: e = x - (W T), masked; sums per row; tile c, register r -> row lk + 4r, column 4 lr + c
         const i64 j0 = c0 + 4 * lr;
+        // a tile with all its rows and columns there, fp32 storage, no array mask (wave-uniform): the same arithmetic without the
+        // per-element edge tests -- those were a branch per element and row in the ISA, hundreds per step
+        // (the builds without row sums only: with them the second epilogue takes the k = 52 masked build past 256 registers)
+        const bool interior = !SUMS && sizeof(SX) == 4 && row0 + 15 < n && c0 + 64 <= (i64)d && (!MASKED || Mb);
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const i64 i = row0 + lk + 4 * r;
+                const unsigned bits = MASKED ? mq[r] >> ((int)(i & 7) << 2) : 0xFu;
+                double ev[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double e = (double)xq[r][c] - acc[c][r];
+                    const double m = MASKED ? (double)((bits >> c) & 1u) : 1.0;
+                    if constexpr (SUMS) {
+                        so[r] += m * e * e;
+                        const double ep = e > 0.0 ? e : 0.0;
+                        sp[r] += ep * ep;
+                    }
+                    ev[c] = MASKED ? m * e : e;
+                }
+                if constexpr (WRITE_E && sizeof(SX) == 4) {
+                    const f32x4 o = f32x4{(float)ev[0], (float)ev[1], (float)ev[2], (float)ev[3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(E + i * lde + j0));
+                }
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const i64 i = row0 + lk + 4 * r;
             if (i >= n) continue;
             unsigned bits = 0xFu;
-            if (MASKED && Mb) bits = Mb[(i >> 3) * ldb + (j0 >> 2)] >> ((int)(i & 7) << 2);
+            if (MASKED && Mb) bits = mq[r] >> ((int)(i & 7) << 2);
             double ev[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -1628,11 +1683,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_resid_mfma(const SX* __restrict_
             }
         }
         if (more) {
-            park(buf ^ 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xq[r][c] = xn[r][c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mq[r] = mn[r];
         }
         __syncthreads();
     }

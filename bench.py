@@ -409,7 +409,7 @@ def main():
     # round 4: the dense weighted flavour takes ONE read-modify-write pass per topic step (E read + written, the mask read:
     # 2 + 1/32 arrays bit-packed, 3 with an fp32 mask) plus, once per sweep, the read-only pass that takes the first column
     # sums after the rebuild (1 + 1/32 or 2 arrays); the timed launches are these k + 1 per sweep.  The pass over the mask
-    # alone between two steps (k_wmcorr, 1/32 of an array) is its own kernel, in the T-row chain's segment.
+    # alone between two steps (k_wmcorr_cols / k_wmcorr, 1/32 of an array) is its own kernel, in the T-row chain's segment.
     wpass_one = weighted and not sparse and os.environ.get('RRI_WPASS_ONE', '1') != '0'
     if wpass_one:
         m_arr = 1.0 / 32.0 if mask_packed else 1.0
@@ -449,8 +449,9 @@ def main():
                    'schedule': ('explicit residual: R <- R - dw t^T - w dt^T, one read-modify-write pass per topic step, R rebuilt '
                                 'once per sweep' if resid_sched else
                                 'maintained masked residual, ONE read-modify-write pass per topic step (both pending rank-one terms, row '
-                                'products, next column sums) + a pass over the bit-packed mask alone for the term the W update leaves '
-                                'pending; rebuilt once per sweep' if wpass_one else
+                                'products, next column sums) + a launch over the bit-packed mask alone for the term the W update leaves '
+                                'pending (a sparse 0/1 mask: a walk over its set bits that takes (w^2)^T M as well); rebuilt once per sweep'
+                                if wpass_one else
                                 'maintained masked residual, two passes per topic step' if weighted
                                 else 'Gram form: one fused read of X per topic step (row dots + next column sums)'
                                      + ('; at this size ONE persistent launch per call with X resident in registers' if

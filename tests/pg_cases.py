@@ -49,6 +49,12 @@ GROUP_CASES = {
     'resets_T_max_resid': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
     'resets_W_random': (600, 200, 4, 2, False, 'float64', dict(t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random', fix_reset_seed=True)),
     'weighted_resets_T': (600, 200, 4, 2, True, 'float64', dict(t_row_sum=1.0, reg_t_l1=1e6)),
+    # T fixed: the W half of all topics is one launch per rank (k_wsweep_rows) and the k column sums travel in ONE all-reduce; a
+    # column that empties in the middle of a launch pauses every rank at that topic, the reset rewrites T[t,:] and W[:,t], and the
+    # sweep resumes at the next topic with X T^T and T T^T taken again
+    'fold_in_resets_W_random': (600, 200, 4, 2, False, 'float64', dict(fix_T=True, t_row_sum=1.0, reg_w_l1=1e6, reset_topic_method='random',
+                                                                     fix_reset_seed=True)),
+    'fold_in_resets_W_max_resid': (600, 200, 4, 2, False, 'float64', dict(fix_T=True, t_row_sum=1.0, reg_w_l1=1e6)),
     # the explicit-residual schedule row-sharded: every rank keeps its rows of R, the reference is the same schedule on one handle
     'residual_schedule_f64': (1501, 700, 6, 3, False, 'float64', dict(schedule='residual')),
     'residual_schedule_f32_tm': (2600, 1200, 7, 3, False, 'float32', dict(schedule='residual', project_T_each_iter=True, t_row_sum=1.0, w_row_sum=1.0)),

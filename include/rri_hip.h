@@ -139,7 +139,13 @@ rri_status rri_set_params(rri_ctx* ctx, const rri_params* p);
  * update).  Returns RRI_OK, RRI_PAUSED (a reset condition of nmf.py:762-783 / :796-816
  * was met: query rri_pending_event, resolve it with rri_apply_reset_* and call
  * rri_resume), or a negative error mirroring the reference's exceptions.
- * sweeps_done (may be NULL) receives the number of COMPLETED sweeps of this call. */
+ * sweeps_done (may be NULL) receives the number of COMPLETED sweeps of this call.
+ * Schedules chosen by the library, same results to summation order and the same events, statuses and resume positions:
+ * launch-bound sizes run as one persistent launch (rri_onchip_info); with fix_T set (the fold-in of nmf.py:417 / 460-476,
+ * sklearn_interface.py:327-333) an unweighted handle takes X T^T and T T^T once per T and runs the W half of all k topics of
+ * a sweep as ONE launch over the rows of W, the column checks of nmf.py:471-476 in topic order after it (k n + k^2 doubles
+ * of device memory more, allocated at the first such sweep; RRI_WSWEEP=0 in the environment of rri_create: topic by topic);
+ * dense weighted handles whose W_mat is 0 / 1 and below 12 % set keep a second bit-packed copy of it (n d / 8 bytes). */
 rri_status rri_sweep(rri_ctx* ctx, int32_t n_sweeps, int32_t* sweeps_done);
 rri_status rri_resume(rri_ctx* ctx, int32_t* sweeps_done);
 rri_status rri_pending_event(rri_ctx* ctx, rri_event* ev);

@@ -183,6 +183,25 @@ def test_fixed_T_whole_sweep_launch_matches_the_launch_per_topic_schedule(monkey
     assert abs(o3 - 0.5 * np.linalg.norm(X - W3 @ T3) ** 2) <= 1e-9 * abs(o3)
 
 
+def test_round4_launches_give_the_same_bits_run_to_run(monkeypatch):
+    """Every sum of the round's new launches has a fixed order (no atomics in the data path): the one-pass weighted step on a
+    sparse 0/1 mask (k_wmcorr_cols, k_wreduce), the whole-sweep W half with T fixed (k_wsweep_rows) and the rebuild with its
+    column ranges (k_resid_mfma) return the same bits from one run to the next."""
+    monkeypatch.setenv('RRI_ONCHIP', '0')
+    n, d, k = 6000, 1300, 7
+    X = planted_X(n, d, k, seed=11, dtype=np.float64)
+    W0, T0 = scaled_init(X, k, seed=12)
+    M = (np.random.RandomState(2).rand(n, d) < 0.05).astype(np.float64)
+    M[0, :] = 1.0
+    runs = []
+    for _ in range(3):
+        a = run_weighted(stored(M * X, np.float32), M, W0, T0, 4, np.float32, t_row_sum=1.0, reset_topic_method=None)
+        b = run_engine(X, W0, T0, 4, np.float32, fix_T=True, reg_w_l1=0.01)
+        runs.append((a[0], a[1], a[2], b[0]))
+    for r in runs[1:]:
+        assert all(np.array_equal(x, y) for x, y in zip(r[:2], runs[0][:2])) and r[2] == runs[0][2] and np.array_equal(r[3], runs[0][3])
+
+
 def test_fixed_T_whole_sweep_launch_halts_where_the_reference_does(monkeypatch):
     """A column of W that the update empties (nmf.py:471-476, 793-816) in the middle of a whole-sweep launch: with a reset method
     the run pauses at that topic with the later columns as they were before the sweep (k_wsweep_repair), the reset is drawn and

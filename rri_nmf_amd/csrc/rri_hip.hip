@@ -2039,7 +2039,11 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
         // config 5, engines made alternately in one process; 24576: the same, 32768: 1.44; the partial column sums grow with the
         // row blocks, +17 us per launch of the T-row chain (profiles/r04_wpass_one_variants.log)
         const bool rmw = explicit_resid || weighted == RRI_WEIGHTED_DENSE;
-        const int total_max = weighted == RRI_WEIGHTED_DENSE ? 16384 : rmw ? 8192 : 2048;
+        // (round 4, late) the read-only pass: at most 1024 -- which at BASELINE config 3 means the LDS cap below decides, 560 rows per
+        // workgroup and 1790 workgroups instead of 496 rows and 2020: 0.647-0.653 against 0.662-0.664 ms in four processes of five,
+        // equal in the fifth (N-way in one process, tools/env_ab.py; the row count is a stride between concurrent streams and
+        // the pass is sensitive to it: 544 rows, between the two, 0.695 ms -- profiles/r04_pass_rows_per_workgroup.log)
+        const int total_max = weighted == RRI_WEIGHTED_DENSE ? 16384 : rmw ? 8192 : 1024;
         const i64 rows_min = weighted == RRI_WEIGHTED_DENSE ? 48 : rmw ? 96 : 192;
         for (int total = total_max; total >= 512 && rpb == 0; total -= 512) {
             const int nrb_t = std::max(1, total / c->npanels);

@@ -2,7 +2,8 @@
 """Two settings of the library's environment switches against each other INSIDE one process (the read-modify-write pass has
 per-process modes that drown an A/B of two processes): the switches are read by rri_create, so engines made alternately under
 setting A and setting B on the same resident X compare like with like.  Pass timed by HIP events.
-    python3 tools/env_ab.py residual|gram|c5 "VAR=1,VAR2=0" "VAR=0" [rounds [timer id: 0 pass, 1 W column, 2 T-row chain, 3 updating pass]]"""
+    python3 tools/env_ab.py residual|gram|c5 "VAR=1,VAR2=0" "VAR=0" [rounds [timer id: 0 pass, 1 W column, 2 T-row chain, 3 updating pass]]
+A setting may be a list "VAR=1|VAR=2|VAR=3": every alternative then takes its turn in every round (N-way, one process)."""
 import os
 import sys
 
@@ -34,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     for rnd in range(rounds):
         row = []
-        for setting in (sa, sb):
+        for setting in [x for part in (sa, sb) for x in part.split('|')]:
             pairs = [kv.split('=') for kv in setting.split(',') if kv]
             for kk, vv in pairs:
                 os.environ[kk] = vv
@@ -54,7 +55,8 @@ def main():
             cnt, ms = eng.timing_read(timer)
             row.append(ms / max(cnt, 1))
             eng.close()
-        print('round %d: [%s] %.4f ms   [%s] %.4f ms' % (rnd, sa, row[0], sb, row[1]), flush=True)
+        names = [x for part in (sa, sb) for x in part.split('|')]
+        print('round %d: ' % rnd + '   '.join('[%s] %.4f ms' % (nm, v) for nm, v in zip(names, row)), flush=True)
 
 
 if __name__ == '__main__':

@@ -61,6 +61,11 @@ class RRIEngine(object):
             raise _capi.RRIHipUnavailable('rri_create failed (%d): %s'
                                           % (st, msg.decode() if msg else '?'))
 
+    def begin_run(self):
+        """a handle kept from an earlier nmf() call starts another one: the per-run counters of the host side"""
+        self.n_resets_used = 0
+        self.reset_log = []
+
     # ---- plumbing -----------------------------------------------------------------------
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:

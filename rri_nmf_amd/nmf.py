@@ -198,6 +198,35 @@ class _ResidentX(object):
         return self._mean
 
 
+class ResidentProblem(object):
+    """Keeps the device handle of an nmf() call -- X uploaded (and, with `preprocess`, rewritten by tf-idf / normalisation), the
+    weights, ||X||^2 -- alive for later calls on the SAME problem: `nmf(X, k, ..., resident=holder)` reuses it when the identity
+    of X and W_mat (the very objects), their shapes and types, k, the storage type, the device, the schedule and the
+    preprocessing asked for are those of the call that made it, and makes (and keeps) a new one otherwise.  What the estimators'
+    `one_iter` loop saves at 100000 x 10000 is the upload and the handle per call (sklearn_interface.py:316-318 re-runs nmf() on
+    the same X every time).  The caller promises not to modify X or W_mat in place between the calls -- nothing here can notice --
+    and closes the holder (`close()`, or its end of life) when done.  Not for row-sharded calls or per-row weights."""
+
+    def __init__(self):
+        self.engine = None
+        self.key = None
+        self.idf = None
+        self.reuses = 0
+
+    def close(self):
+        if self.engine is not None:
+            try:
+                self.engine.close()
+            finally:
+                self.engine, self.key, self.idf = None, None, None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 def _preprocess_spec(preprocess):
     """(tfidf, normalize) of the `preprocess` option: None, a dict {'tfidf': True | idf vector | False,
     'normalize': bool}, or a string / sequence naming the steps ('tfidf', 'normalize')"""
@@ -376,7 +405,8 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         reg_w_l2=0, reg_t_l2=0, reg_w_l1=0, reg_t_l1=0,
         diagnostics=[], store_gradients=False,
         ind_rows_to_store=None, eps_gauss_t=None, delta_gauss_t=None,
-        *, dtype=None, device=0, device_init=None, sparse_pattern=None, preprocess=None, schedule='gram', group=None):
+        *, dtype=None, device=0, device_init=None, sparse_pattern=None, preprocess=None, schedule='gram', group=None,
+        resident=None):
     """Non-negative factorisation X ~ W T by rank-one residue iteration; see the module docstring and
     the reference's docstring (nmf.py:109-269) for the parameters.  Returns a dict with 'W', 'T',
     'iter_cputime' (wall seconds since the start, per sweep), 'random_state' and, when the objective
@@ -385,7 +415,9 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
     preprocess (keyword only, not in the reference's signature): tf-idf and / or row normalisation of X
     (matrixops.py:124-179) before the factorisation -- {'tfidf': True | idf vector | False, 'normalize': bool} or
     the step names.  A dense X without weights or host callbacks is uploaded raw and rewritten in place on the
-    device; every other case preprocesses on the host.  The idf used comes back as rtv['idf']."""
+    device; every other case preprocesses on the host.  The idf used comes back as rtv['idf'].
+    resident (keyword only): a ResidentProblem that keeps the device handle -- X uploaded and preprocessed -- from one call to
+    the next on the same problem (see there)."""
     if group is not None:
         # host work that would need the other ranks' rows (the SVD behind the NNDSVD start, document frequencies,
         # per-row weights with their refit) or that decides per rank (callbacks) is not part of the sharded call
@@ -412,6 +444,7 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         sigma2 = c2 * df2 ** 2 * (1 / float(eps_gauss_t)) ** 2
         noise = gaussian(0, np.sqrt(sigma2))            # draws from numpy's global RNG, as the reference's does
         draw_noise = lambda m: np.asarray(noise.rvs(m), dtype=np.float64).ravel()
+    X_given, W_mat_given = X, W_mat
     # scipy sparse X / 0-1 sparse W_mat are ingested as CSR (no host densification); row weights need a dense X
     if scipy.sparse.issparse(X):
         X = X.tocsr() if w_row is None else X.toarray()
@@ -486,18 +519,40 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
         raise NotImplementedError("schedule='residual' belongs to the unweighted flavour (the weighted one always keeps its masked residual)")
     # fix_W / fix_T / k = 1 on a handle of the explicit-residual schedule: one half of every step is missing, and the library
     # steps such calls in the Gram form (T fixed: X T^T once, no pass over the matrix per topic) -- fold-in works on either handle
-    eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern, schedule)
+    # a handle kept from an earlier call on the same problem (ResidentProblem): the same objects, shapes, types and options
+    res_key = None
+    if resident is not None:
+        if group is not None or w_row is not None or (spec is not None and device_spec is None):
+            raise ValueError('resident= keeps a handle for plain calls: no group, no w_row, no host-side preprocessing')
+        tf_opt = None if device_spec is None else (device_spec['tfidf'] if isinstance(device_spec['tfidf'], bool) else 'given')
+        res_key = (id(X_given), tuple(X.shape), str(getattr(X, 'dtype', None)), None if W_mat_given is None else id(W_mat_given),
+                   int(k), str(sdt), device, sparse_pattern, schedule,
+                   None if device_spec is None else (tf_opt, bool(device_spec['normalize'])))
+        if tf_opt == 'given':
+            res_key = None               # an idf vector from outside: not worth telling apart -- a fresh handle
+    reused = resident is not None and resident.engine is not None and res_key is not None and resident.key == res_key
+    if reused:
+        eng = resident.engine
+        eng.begin_run()
+        resident.reuses += 1
+    else:
+        if resident is not None:
+            resident.close()
+        eng = _engine_with_problem(X, W_mat, k, sdt, device, sparse_pattern, schedule)
+    keep_handle = False
     try:
         if group is not None:
             eng.attach_group(group)
         on_device = device_init if device_init is not None else (float(n) * d >= DEVICE_INIT_MIN_ELEMS)
         X_init = X
         if device_spec is not None:
-            idf = eng.preprocess(**device_spec)
+            idf = resident.idf if reused else eng.preprocess(**device_spec)
             rtv['idf'] = idf
             device_spec = {'tfidf': idf if idf is not None else False, 'normalize': device_spec['normalize']}
             on_device = True                 # the preprocessed X exists only on the device
             X_init = _ResidentX(eng)
+        if resident is not None and res_key is not None and not reused:
+            resident.engine, resident.key, resident.idf = eng, res_key, rtv.get('idf')
         W, T = _initialize_and_validate(W_in=W_in, T_in=T_in, W_mat=W_mat, X=X_init, k=k, init=init,
                                         random_state=random_state, project_T_each_iter=project_T_each_iter,
                                         project_W_each_iter=project_W_each_iter, w_row_sum=w_row_sum,
@@ -638,8 +693,14 @@ def nmf(X, k, w_row=None, W_mat=None, fix_W=False, fix_T=False,
 
         W, T = current()
         n_resets_used = eng.n_resets_used
+        keep_handle = resident is not None and resident.engine is eng
     finally:
-        eng.close()
+        if keep_handle:
+            pass                         # the holder's from here on
+        elif resident is not None and resident.engine is eng:
+            resident.close()             # the call failed: a handle in an unknown state is not kept
+        else:
+            eng.close()
 
     if w_row is not None:                        # nmf.py:531-539: refit W on the unweighted rows
         sub = nmf(X_orig, k, T_in=T, fix_T=True, max_iter=10, w_row_sum=w_row_sum,

@@ -195,7 +195,12 @@ class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.Tra
     def __init__(self, n, d, k, wr1=0, wr2=0, tr1=0, tr2=0, random_state=0,
                  handle_tfidf=False, handle_normalization=False, max_iter=300,
                  W=np.array([]), T=np.array([]), nmf_kwargs={},
-                 do_final_project_W=True):
+                 do_final_project_W=True, keep_resident=False):
+        # keep_resident (not in the reference): fit / one_iter on the SAME array X keep its device handle -- X uploaded and
+        # preprocessed -- between the calls (nmf.ResidentProblem; the caller must not modify X in place meanwhile); release()
+        # frees it
+        self.keep_resident = keep_resident
+        self._resident = None
         self.n, self.d, self.k = n, d, k
         self.wr1, self.wr2, self.tr1, self.tr2 = wr1, wr2, tr1, tr2
         self.random_state = random_state
@@ -217,6 +222,10 @@ class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.Tra
     def _solve(self, X, max_iter, max_time):
         W_in, T_in = self._warm_start()
         kw = dict(self._preprocess_kwargs(), **self.nmf_kwargs)
+        if self.keep_resident and not sp.issparse(X):
+            if self._resident is None:
+                self._resident = _nmf_module.ResidentProblem()
+            kw['resident'] = self._resident
         soln = _nmf(X, self.k, max_iter=max_iter, max_time=max_time, project_W_each_iter=False,
                     w_row_sum=1.0, project_T_each_iter=True, t_row_sum=1.0,
                     do_final_project_W=self.do_final_project_W, W_in=W_in, T_in=T_in,
@@ -225,6 +234,11 @@ class NMF_TM_Estimator(_FactorPair, sklearn.base.BaseEstimator, sklearn.base.Tra
         if self.handle_tfidf:
             self.idf = soln['idf']
         self._keep(soln)
+
+    def release(self):
+        """free the device handle kept by keep_resident"""
+        if self._resident is not None:
+            self._resident.close()
 
     def fit_transform(self, X, y=None):
         assert _all_nonnegative(X), 'X must be non-negative'

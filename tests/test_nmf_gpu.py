@@ -76,6 +76,57 @@ def test_convergence_TM_Estimator():
     assert Wte is not None and M3.constrained_transform(g['Xte']).shape == Wte.shape
 
 
+@pytest.mark.parametrize('prep', [False, True])
+def test_resident_handle_between_fit_and_one_iter(monkeypatch, prep):
+    """keep_resident (round 4; sklearn_interface.py:316-318 re-runs nmf() on the same X for every one_iter): the handle of fit --
+    X uploaded and, with handle_tfidf / handle_normalization, rewritten on the device -- serves the one_iter calls that follow on
+    the same array: ONE upload, the same bits as the estimator that makes a handle per call; another array, or an array of
+    another shape, gets a handle of its own; release() frees it; a call that raises leaves no handle behind."""
+    nmf_mod, si = api()
+    from rri_nmf_amd.engine import RRIEngine
+    g = load_golden('g1_tm_estimator')
+    X = np.ascontiguousarray(g['X'])
+    n, d = X.shape
+    uploads = []
+    real_upload = RRIEngine.upload_X
+    monkeypatch.setattr(RRIEngine, 'upload_X', lambda self, A: (uploads.append(A.shape), real_upload(self, A))[1])
+    kw = dict(random_state=0, max_iter=3, do_final_project_W=False, handle_tfidf=prep, handle_normalization=prep,
+              nmf_kwargs={'eps_stop': -1})
+    plain = si.NMF_TM_Estimator(n, d, 5, **kw).fit(X)
+    for _ in range(3):
+        plain = plain.one_iter(X)
+    n_plain = len(uploads)
+    del uploads[:]
+    kept = si.NMF_TM_Estimator(n, d, 5, keep_resident=True, **kw).fit(X)
+    for _ in range(3):
+        kept = kept.one_iter(X)
+    assert n_plain == 4 and len(uploads) == 1 and kept._resident.reuses == 3
+    assert np.array_equal(kept.W, plain.W) and np.array_equal(kept.T, plain.T)
+    assert kept.nmf_outputs['obj_history'] == plain.nmf_outputs['obj_history']
+    if prep:
+        assert np.array_equal(kept.idf, plain.idf)
+    # another array (same values): a handle of its own, and it becomes the resident one
+    X2 = X.copy()
+    kept.one_iter(X2)
+    assert len(uploads) == 2 and kept._resident.reuses == 3
+    kept.one_iter(X2)
+    assert len(uploads) == 2 and kept._resident.reuses == 4
+    # the holder used directly; a failing call drops the handle
+    holder = nmf_mod.ResidentProblem()
+    r1 = nmf_mod.nmf(X, 5, max_iter=2, random_state=0, eps_stop=-1, resident=holder)
+    r2 = nmf_mod.nmf(X, 5, max_iter=2, random_state=0, eps_stop=-1, resident=holder)
+    assert holder.reuses == 1 and np.array_equal(r1['W'], r2['W']) and np.array_equal(r1['T'], r2['T'])
+    with pytest.raises(ValueError):
+        nmf_mod.nmf(X, 5, max_iter=2, random_state=0, W_in=np.ones((3, 3)), T_in=np.ones((5, d)), resident=holder)
+    r3 = nmf_mod.nmf(X, 5, max_iter=2, random_state=0, eps_stop=-1, resident=holder)
+    assert np.array_equal(r3['W'], r1['W'])
+    with pytest.raises(ValueError):
+        nmf_mod.nmf(X, 5, w_row=np.ones((n, 1)), resident=holder)
+    holder.close()
+    kept.release()
+    assert holder.engine is None and kept._resident.engine is None
+
+
 def test_logger_level_switches_objective_tracking():
     nmf_mod, _ = api()
     X = planted_X(200, 120, 4, dtype=np.float64)

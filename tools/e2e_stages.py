@@ -85,3 +85,17 @@ print('\ntransform of 5000 documents (float64 storage): %.2f s' % (time.perf_cou
 for label, v in acc.items():
     print('    %-52s %7.3f s' % (label, v))
 assert abs(W.sum(1) - 1).max() < 1e-9
+
+# one more sweep per call on the same array (one_iter, sklearn_interface.py:316-318): a handle per call against keep_resident
+for keep in (False, True):
+    est = si.NMF_TM_Estimator(n, d, k, random_state=0, max_iter=2, handle_tfidf=True, handle_normalization=True, keep_resident=keep,
+                              nmf_kwargs={'dtype': np.float32, 'eps_stop': -1}).fit(X)
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        est.one_iter(X)
+        times.append(time.perf_counter() - t0)
+    print('\none_iter on the same 100000 x 10000 array, fp32 storage, %s: %s s per call'
+          % ('keep_resident=True (one handle, X stays on the device)' if keep else 'a handle per call (upload + preprocessing every time)',
+             ' '.join('%.3f' % v for v in times)))
+    est.release()

@@ -145,7 +145,10 @@ rri_status rri_set_params(rri_ctx* ctx, const rri_params* p);
  * sklearn_interface.py:327-333) an unweighted handle takes X T^T and T T^T once per T and runs the W half of all k topics of
  * a sweep as ONE launch over the rows of W, the column checks of nmf.py:471-476 in topic order after it (k n + k^2 doubles
  * of device memory more, allocated at the first such sweep; RRI_WSWEEP=0 in the environment of rri_create: topic by topic);
- * dense weighted handles whose W_mat is 0 / 1 and below 12 % set keep a second bit-packed copy of it (n d / 8 bytes). */
+ * dense weighted handles whose W_mat is 0 / 1 and below 12 % set keep a second bit-packed copy of it (n d / 8 bytes);
+ * handles that keep a residual (RRI_UNWEIGHTED_RESIDUAL, dense weighted) of 10^8 elements or more time their read-modify-write
+ * pass once, before the first sweep, under the two ways of dealing its tiles to the XCDs and keep the faster (~12 ms; the
+ * residual is rewritten with its own values meanwhile; RRI_ROT_CAL=0: not). */
 rri_status rri_sweep(rri_ctx* ctx, int32_t n_sweeps, int32_t* sweeps_done);
 rri_status rri_resume(rri_ctx* ctx, int32_t* sweeps_done);
 rri_status rri_pending_event(rri_ctx* ctx, rri_event* ev);
@@ -316,6 +319,8 @@ rri_status rri_onchip_info(rri_ctx* ctx, int32_t* eligible, int64_t* launches);
  * *eligible of rri_onchip_info and RRI_ERR_UNSUPPORTED of rri_sweep_until therefore depend on the clock after a fallback.
  * *fallbacks: how often that happened on this handle. */
 rri_status rri_onchip_fallbacks(rri_ctx* ctx, int64_t* fallbacks);
+/* diagnostics: the XCD (XCC_ID) each of `count` workgroups of a launch on the handle's stream lands on */
+rri_status rri_debug_xcc(rri_ctx* ctx, int32_t* out, int32_t count);
 /* The sweep / objective / stop-rule loop of nmf.py:377-516 for launch-bound sizes, in one call: up to n_sweeps sweeps of the
  * register-resident kernel with the objective of every sweep kept (true_objective, nmf.py:71-94, 488-490) and the rule of
  * nmf.py:510 / optimization.py:284-291 applied ON THE DEVICE after every sweep: the run ends after the first sweep s with

@@ -105,6 +105,7 @@ PROTOTYPES = {
     'rri_timing_read': (_I32, [_P, _I32, C.POINTER(_I64), C.POINTER(_D)]),
     'rri_onchip_info': (_I32, [_P, C.POINTER(_I32), C.POINTER(_I64)]),
     'rri_onchip_fallbacks': (_I32, [_P, C.POINTER(_I64)]),
+    'rri_debug_xcc': (_I32, [_P, C.POINTER(_I32), _I32]),
     'rri_sweep_until': (_I32, [_P, _I32, _D, _D, C.POINTER(_D), C.POINTER(_I32)]),
     'rri_synchronize': (_I32, [_P]),
     'rri_bench_rank1_update': (_I32, [_P, _I32, C.POINTER(_D)]),

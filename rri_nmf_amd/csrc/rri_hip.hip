@@ -140,6 +140,10 @@ struct rri_ctx {
     i64 ldb = 0;
     double* Qt = nullptr;     // X T^T (k x n), valid while T is fixed
     bool q_valid = false;
+    // tile -> XCD rotation of the passes over X (read only) and over the stored residual (read-modify-write): 0 or 1, the faster
+    // of the two for THIS handle's buffers (calibrate_rot); RRI_PASS_ROT forces one for all
+    int rot_x = 0, rot_r = 0;
+    bool rot_done = false;
     bool gfull_valid = false;   // Gfull = T T^T of the current T (k_wsweep_rows)
     double *Gfull = nullptr, *Wsweep0 = nullptr, *wsum_part = nullptr, *wsums = nullptr;   // whole-sweep W half with T fixed: lazily allocated
     double *Y2part = nullptr, *Z2part = nullptr, *dtv = nullptr, *dwv = nullptr, *wold = nullptr, *zeros = nullptr;  // weighted
@@ -469,7 +473,10 @@ int g_wsweep = 1;        // RRI_WSWEEP=0: runs with T fixed take the launch-per-
 int g_trow_small = 1;    // RRI_TROW_SMALL=0: k_reduce + k_trow_numer as two launches at every size
 int g_pass_interleave = -1;  // RRI_PASS_IL: 1 / 0 = interleaved / contiguous row chunks per workgroup of k_pass; default:
                              // interleaved up to 1024 workgroups (+2 % at 20000 x 5000; -1 % at C3, where it stays off)
-int g_pass_rot = 0;      // RRI_PASS_ROT=1..7 (diagnostics): rotate the tiles of k_pass inside every group of 8 workgroups (another XCD per tile)
+int g_pass_rot = -1;     // RRI_PASS_ROT=0..7: rotate the tiles of the passes inside every group of 8 workgroups (another XCD per tile) by this much
+                         // for every handle; unset: each handle's own calibrated 0 or 1 (calibrate_rot)
+int g_rot_cal = 1;       // RRI_ROT_CAL=0: no calibration, rotation 0
+int g_rmw_shop = 1;      // RRI_RMW_SHOP=n (diagnostics): places a large residual buffer is tried in (calibrate_rot); 1: the first allocation is kept
 int g_obj_direct = 0;   // RRI_OBJ_DIRECT=1: the objective always through the residual (k_resid)
 // kernels that touch X / mask / residual depend on the storage type SX; the rest is float64
 template <typename SX>
@@ -502,7 +509,8 @@ struct LaunchX {
                            // linear stream does.  Read-only pass: +2 % up to 1024 workgroups, nothing at C3.  Read-modify-write
                            // (UPD): +4-9 % at C3 (profiles/r02_residual_schedule_geometry.log) -- reads and writes of a window
                            // stay in the DRAM pages that are open
-                           ((g_pass_interleave == 1 || (g_pass_interleave < 0 && (c->npanels * c->nrb <= 1024 || UPD > 0))) ? c->nrb : 0) | (g_pass_rot << 27));
+                           ((g_pass_interleave == 1 || (g_pass_interleave < 0 && (c->npanels * c->nrb <= 1024 || UPD > 0))) ? c->nrb : 0) |
+                               ((g_pass_rot >= 0 ? g_pass_rot : (UPD > 0 ? c->rot_r : c->rot_x)) << 27));
     }
     // the read-only pass through the LDS-DMA ring (k_pass_dma), opt-in (RRI_PASS_DMA=1): where the ring and the row-dot slots fit
     // the LDS and X's rows are 16-byte aligned
@@ -611,7 +619,7 @@ struct LaunchX {
                                    dim3(256), (11 * (size_t)c->rpb + 4 * 8 * 72) * sizeof(double), c->stream, (SX*)c->E,
                                    (const SX*)c->M, c->LD, c->ldm, (const unsigned*)c->Mbits, c->ldb, (int)c->n, ncols, trow,
                                    wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
-                                   (const DevState*)c->st, (g_wpass_il == 1 || g_wpass_il < 0) ? c->nrb : 0);
+                                   (const DevState*)c->st, ((g_wpass_il == 1 || g_wpass_il < 0) ? c->nrb : 0) | ((g_pass_rot >= 0 ? g_pass_rot : c->rot_r) << 27));
                 return;
             }
         }
@@ -621,7 +629,8 @@ struct LaunchX {
                            wc, a1, b1, a2, b2, c->Ypart, c->Y2part, c->Zpart, c->Z2part, c->LD, c->rpb, c->npanels,
                            (const DevState*)c->st,
                            // interleaved row chunks for the passes that write E back (read-modify-write), as for k_pass<UPD>
-                           (g_wpass_il == 1 || (g_wpass_il < 0 && (WRITE || c->npanels * c->nrb <= 1024))) ? c->nrb : 0);
+                           ((g_wpass_il == 1 || (g_wpass_il < 0 && (WRITE || c->npanels * c->nrb <= 1024))) ? c->nrb : 0) |
+                               ((g_pass_rot >= 0 ? g_pass_rot : c->rot_r) << 27));
     }
     template <bool DO_Y, bool DO_Z, bool UPD2, bool WRITE>
     static void wpass(rri_ctx* c, const double* trow, const double* wc, const double* a1, const double* b1,
@@ -1512,6 +1521,111 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
     c->carry_topic = tn;
 }
 
+// ---- which XCD gets which tile: the two speeds of the read-modify-write passes -------------------------------------------------
+// The pass over a handle's stored residual runs at one of two speeds -- 1.35 against 1.50-1.57 ms for the rank-one update of
+// BASELINE config 3, 1.39-1.41 against 1.55 ms for the weighted one-pass step -- and rounds 2-4 could only report which one a
+// process had caught.  What decides it is which XCD is dealt which tile: the workgroups of a launch go round-robin over the 8
+// XCDs, and rotating the tiles by ONE inside every group of 8 workgroups flips the speed -- every odd rotation fast and every
+// even one slow, or the other way round in another process (tools/xcc_mode_probe.py, profiles/r04_xcc_mode_probe.log: the
+// buffer's placement against the memory side's interleave, one would think; nothing a process can read).  So a handle that
+// keeps a residual TIMES both before its first sweep: per rotation three null updates (a = 0: the residual is rewritten with
+// its own values, bit for bit), the last two timed -- ~10 ms once per handle -- and keeps the faster.  The rotation changes
+// which workgroup computes a tile and nothing in any sum: the results are the same bits whichever wins.
+// (The read-only pass over X differs by 1 % between the two; it keeps rotation 0.)
+hipError_t big_malloc(void** p, size_t bytes);
+void calibrate_rot(rri_ctx* c) {
+    if (c->rot_done) return;
+    c->rot_done = true;
+    if (g_pass_rot >= 0 || !g_rot_cal) return;
+    const bool resid = c->explicit_resid && !c->weighted;
+    const bool wdense = c->weighted && !c->sparse;
+    if (!(resid || wdense) || (double)c->n * (double)c->d < 1.0e8 || c->npanels * c->nrb < 64) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return; }
+    auto refresh = [&]() {
+        if (resid) r_refresh(c);
+        else w_refresh(c);
+    };
+    if (!c->resid_valid) refresh();
+    // one buffer: the better of the rotations 0 and 1 (or 0 .. RRI_ROT_CAL-1), by null updates; < 0: a launch or a wait failed
+    auto time_buffer = [&](int* rot_out) -> float {
+        float best = -1.0f;
+        const int nrot = g_rot_cal > 1 ? std::min(g_rot_cal, 8) : 2;
+        for (int rot = 0; rot < nrot; ++rot) {
+            c->rot_r = rot;
+            for (int rep = 0; rep < 3; ++rep) {
+                if (rep == 1) (void)hipEventRecord(e0, c->stream);
+                if (resid) {
+                    DISPATCH(c, {
+                        typename L::Upd u;
+                        u.a = c->zeros; u.b = c->zeros; u.a2 = c->zeros; u.b2 = c->zeros; u.b2sub = c->zeros;
+                        L::rank_update(c, c->E, c->LD, u, c->T, c->W);
+                    });
+                } else {
+                    DISPATCH(c, (L::template wpass<true, true, true, true>(c, c->T, c->W, c->zeros, c->zeros, c->zeros, c->zeros)));
+                }
+            }
+            (void)hipEventRecord(e1, c->stream);
+            float ms = 0.0f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0f;
+            if (getenv("RRI_ROT_DEBUG")) fprintf(stderr, "rri: tile rotation %d: %.4f ms per null update\n", rot, ms / 2.0f);
+            if (best < 0.0f || ms < best) { best = ms; *rot_out = rot; }
+        }
+        return best;
+    };
+    // The level under the parity belongs to the BUFFER, not to the process (six residuals alive in one process: one at 1.34 ms,
+    // one at 1.42, four at 1.50-1.53 whatever the rotation; physically contiguous memory: always 1.54 --
+    // profiles/r04_rmw_buffer_probe.log).  RRI_RMW_SHOP=n (diagnostics, default 1 = off) tries a large residual in up to n
+    // places -- a new allocation while the ones before it are still held, the residual rebuilt into it, timed -- until one runs
+    // 7 % faster than the slowest seen, keeps the best and frees the others: on a box whose buffers are slow it found none in
+    // 40 places (10 processes), which is why it is not the default.
+    const size_t ebytes = (size_t)c->n * (size_t)c->LD * (c->dtype == RRI_F32 ? 4 : 8);
+    const int places = ebytes >= ((size_t)1 << 30) ? std::max(1, g_rmw_shop) : 1;
+    std::vector<void*> held;
+    void* best_e = c->E;
+    int best_rot = 0, rot = 0;
+    c->rot_r = 0;
+    for (int rep = 0; rep < 2; ++rep) {        // (the first passes of a process run ~5 % slow: not the rotation's doing)
+        if (resid) {
+            DISPATCH(c, {
+                typename L::Upd u;
+                u.a = c->zeros; u.b = c->zeros; u.a2 = c->zeros; u.b2 = c->zeros; u.b2sub = c->zeros;
+                L::rank_update(c, c->E, c->LD, u, c->T, c->W);
+            });
+        } else {
+            DISPATCH(c, (L::template wpass<true, true, true, true>(c, c->T, c->W, c->zeros, c->zeros, c->zeros, c->zeros)));
+        }
+    }
+    float best_ms = time_buffer(&rot), worst_ms = best_ms;
+    best_rot = rot;
+    for (int a = 1; a < places && best_ms > 0.0f; ++a) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * ebytes + ((size_t)4 << 30)) break;
+        void* p = nullptr;
+        if (big_malloc(&p, ebytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (c->LD != c->d) (void)hipMemsetAsync(p, 0, ebytes, c->stream);      // pad columns stay zero
+        held.push_back(c->E);
+        c->E = p;
+        refresh();
+        const float ms = time_buffer(&rot);
+        if (getenv("RRI_ROT_DEBUG")) fprintf(stderr, "rri: residual buffer %d: %.4f ms (the first %.4f)\n", a, ms / 2.0f, worst_ms / 2.0f);
+        if (ms < 0.0f) break;
+        worst_ms = std::max(worst_ms, ms);
+        if (ms < best_ms) { best_ms = ms; best_rot = rot; best_e = c->E; }
+        if (best_ms < 0.93f * worst_ms) break;
+    }
+    held.push_back(c->E);
+    for (void* p : held)
+        if (p != best_e) (void)hipFree(p);
+    c->E = best_e;                 // (its content: the residual of the current W, T -- the null updates rewrote it with itself)
+    c->rot_r = best_ms > 0.0f ? best_rot : 0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c->carry_valid = false;          // the null updates left their own row products and column sums in the scratch arrays
+    c->carry_topic = -1;
+}
+
 // ---- T fixed: the W half of all topics of a sweep as one launch (k_wsweep_rows) ---------------------------------------
 bool wsweep_ok(const rri_ctx* c) {
     return g_wsweep && c->prm.fix_T && !c->prm.fix_W && !c->weighted && !c->sparse && c->k >= 1 &&
@@ -1571,6 +1685,7 @@ bool enqueue_wsweep(rri_ctx* c, int sweep, int t0) {
 // sweeps [cur .. s_end) of the current call
 void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
     const int k = c->k;
+    if (cur.sweep < s_end && (c->weighted || resid_sched(c))) calibrate_rot(c);
     if (c->weighted) {
         for (int s = cur.sweep; s < s_end; ++s) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;
@@ -1994,8 +2109,12 @@ rri_status rri_create(rri_ctx** out, int64_t n, int64_t d, int32_t k, int32_t dt
     if (const char* e = getenv("RRI_ONCHIP")) g_onchip = atoi(e) != 0;
     if (const char* e = getenv("RRI_ONCHIP_OBJ")) g_onchip_obj = atoi(e) != 0;
     g_onchip_coop = 0;
-    g_pass_rot = 0;
+    g_pass_rot = -1;
     if (const char* e = getenv("RRI_PASS_ROT")) g_pass_rot = atoi(e) & 7;
+    g_rot_cal = 1;
+    g_rmw_shop = 1;
+    if (const char* e = getenv("RRI_RMW_SHOP")) g_rmw_shop = std::min(12, std::max(1, atoi(e)));
+    if (const char* e = getenv("RRI_ROT_CAL")) g_rot_cal = std::max(0, atoi(e));      // 0 off, 1 rotations {0, 1}, n > 1: rotations 0 .. n-1
     g_malloc_contig = 0;
     if (const char* e = getenv("RRI_MALLOC_CONTIGUOUS")) g_malloc_contig = atoi(e) != 0;
     if (const char* e = getenv("RRI_ONCHIP_COOP")) g_onchip_coop = atoi(e) != 0;
@@ -3638,6 +3757,18 @@ rri_status rri_onchip_info(rri_ctx* c, int32_t* eligible, int64_t* launches) {
     CHECK_CTX(c);
     if (eligible) *eligible = (c->have_X && c->have_params && onchip_ok(c)) ? 1 : 0;
     if (launches) *launches = c->onchip_launches;
+    return RRI_OK;
+}
+
+rri_status rri_debug_xcc(rri_ctx* c, int32_t* out, int32_t count) {
+    CHECK_CTX(c);
+    if (!out || count < 1 || count > 4096) return fail(c, RRI_ERR_INVALID, "bad count");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevTmp dv;
+    HIPCHK(c, dv.alloc((size_t)count * sizeof(int)));
+    hipLaunchKernelGGL(k_xcc_probe, dim3((unsigned)count), dim3(64), 0, c->stream, (int*)dv.p);
+    HIPCHK(c, hipMemcpyAsync(out, dv.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RRI_OK;
 }
 

@@ -2053,6 +2053,13 @@ __global__ __launch_bounds__(256) void k_convert2d(const Src* __restrict__ src, 
 }
 
 // plain 16-byte streaming copy: the achievable-HBM yardstick measured beside the pass kernel
+// diagnostics: which XCD (accelerator complex die) each workgroup of a launch on this stream lands on -- out[blockIdx] = XCC_ID
+__global__ __launch_bounds__(64) void k_xcc_probe(int* __restrict__ out) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(v & 0xfu);
+}
+
 __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, i64 nvec) {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (i64)gridDim.x * 256) dst[i] = src[i];
 }

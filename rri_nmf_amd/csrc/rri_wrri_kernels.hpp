@@ -123,7 +123,7 @@ __device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restr
                                            const double* __restrict__ a2v, const double* __restrict__ b2v,
                                            double* __restrict__ Ypart, double* __restrict__ Y2part,
                                            double* __restrict__ Zpart, double* __restrict__ Z2part, i64 ldz,
-                                           int rpb, int npg, const DevState* __restrict__ st, int nrb_il) {
+                                           int rpb, int npg, const DevState* __restrict__ st, int nrb_il_rot) {
     typedef XVec<SX> XV;
     typedef typename XV::type V;
     constexpr int VN = XV::N;
@@ -139,7 +139,13 @@ __device__ __forceinline__ void wpass_body(SX* __restrict__ E, const SX* __restr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* tile = a2sh + rpb + wave * (8 * 72);     // [4][8*72] private row-sum tiles (RS)
-    const int pg = blockIdx.x % npg, rb = blockIdx.x / npg;
+    // (top bits of the last argument: the tile a workgroup takes inside its group of 8, rotated -- another XCD for every tile,
+    // nothing else changed; the handle's calibrated value, see calibrate_rot in rri_hip.hip)
+    const int rot = (int)(((unsigned)nrb_il_rot >> 27) & 7u);
+    const int nrb_il = nrb_il_rot & 0x07ffffff;
+    int bid = (int)blockIdx.x;
+    if (rot != 0 && (bid | 7) < (int)gridDim.x) bid = (bid & ~7) | ((bid + rot) & 7);
+    const int pg = bid % npg, rb = bid / npg;
     // rows of this block, local index li -> global row: contiguous (rb rpb + li), or -- nrb_il > 0 -- chunk q of U rows is
     // chunk q nrb + rb of the matrix, so the workgroups running at one time walk ONE window of E as a linear stream does
     // (what made the read-modify-write pass of the unweighted residual schedule 4-9 % faster, k_pass)

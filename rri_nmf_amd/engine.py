@@ -606,6 +606,12 @@ class RRIEngine(object):
         self._check(self._lib.rri_onchip_info(self._h, C.byref(el), C.byref(n)))
         return bool(el.value), int(n.value)
 
+    def debug_xcc(self, count=32):
+        """diagnostics: the XCD each of `count` workgroups of a launch on this handle's stream lands on"""
+        out = (C.c_int32 * count)()
+        self._check(self._lib.rri_debug_xcc(self._h, out, count))
+        return list(out)
+
     def onchip_fallbacks(self):
         """how many persistent launches of this handle gave up (workgroups not co-resident) and were rerun launch by launch"""
         n = C.c_int64(0)

@@ -14,7 +14,7 @@ from bench import device_planted_shard          # noqa: E402
 from rri_nmf_amd.engine import RRIEngine        # noqa: E402
 
 os.environ['RRI_ROT_DEBUG'] = '1'
-os.environ['RRI_ROT_CAL'] = '8'
+os.environ.setdefault('RRI_ROT_CAL', '8')
 n, d, k = 100000, 10000, 50
 dev = torch.device('cuda', 0)
 X = device_planted_shard(n, d, k, 0, dev)

@@ -268,3 +268,47 @@ def test_nmf_with_the_residual_schedule_on_the_text_fixture():
     M = si.NMF_TM_Estimator(n, d, 5, random_state=0, max_iter=10, nmf_kwargs={'eps_stop': -1, 'schedule': 'residual'}).fit(X)
     Wte = M.transform(g['Xte'])
     assert relfro(Wte, g['Wte']) < 1e-7 and np.array_equal(np.argmax(Wte, 1), g['argmax_te'])
+
+
+def test_tile_rotation_is_calibrated_per_handle_and_changes_no_bit(monkeypatch, capfd):
+    """calibrate_rot (round 4): a handle that keeps a residual of 10^8 elements or more times its read-modify-write pass under the
+    two ways of dealing its tiles to the XCDs before the first sweep (null updates: the residual rewritten with its own values)
+    and keeps the faster.  The rotation decides which workgroup computes a tile and nothing in any sum: the explicit-residual
+    schedule and the dense weighted flavour return the same bits with the calibration on (default), off, and with either rotation
+    forced; RRI_ROT_DEBUG shows that the calibration ran, once per handle."""
+    from rri_nmf_amd.engine import RRIEngine
+    n, d, k = 26000, 4000, 6                       # 1.04e8 elements: the smallest size class that calibrates
+    X = planted_X(n, d, k, seed=21, dtype=np.float32)
+    W0, T0 = scaled_init(X.astype(np.float64), k, seed=22)
+    M = (np.random.RandomState(3).rand(n, d) < 0.08).astype(np.float32)
+    M[0, :] = 1.0
+    monkeypatch.setenv('RRI_ONCHIP', '0')
+
+    def run(kind, **env):
+        for key in ('RRI_ROT_CAL', 'RRI_PASS_ROT', 'RRI_ROT_DEBUG'):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        if kind == 'residual':
+            e = RRIEngine(n, d, k, dtype=np.float32, schedule='residual')
+            e.upload_X(X)
+            flags = {}
+        else:
+            e = RRIEngine(n, d, k, dtype=np.float32, weighted=True)
+            e.upload_X(X * M)
+            e.upload_mask(M)
+            flags = dict(t_row_sum=1.0, reset_topic_method=None)
+        with e:
+            e.set_W(W0); e.set_T(T0); e.set_params(**flags)
+            e.sweep(1)
+            e.sweep(1)
+            return e.get_W(), e.get_T(), e.objective()
+
+    for kind in ('residual', 'weighted'):
+        capfd.readouterr()
+        base = run(kind, RRI_ROT_DEBUG='1')
+        err = capfd.readouterr().err
+        assert err.count('tile rotation 0:') == 1 and err.count('tile rotation 1:') == 1, err      # once per handle, not per sweep
+        for env in (dict(RRI_ROT_CAL='0'), dict(RRI_PASS_ROT='0'), dict(RRI_PASS_ROT='1'), dict(RRI_PASS_ROT='3')):
+            other = run(kind, **env)
+            assert np.array_equal(other[0], base[0]) and np.array_equal(other[1], base[1]) and other[2] == base[2], (kind, env)

@@ -1531,18 +1531,44 @@ void enqueue_wW_half(rri_ctx* c, int sweep, int t, bool defer_check = false) {
 // keeps a residual TIMES both before its first sweep: per rotation three null updates (a = 0: the residual is rewritten with
 // its own values, bit for bit), the last two timed -- ~10 ms once per handle -- and keeps the faster.  The rotation changes
 // which workgroup computes a tile and nothing in any sum: the results are the same bits whichever wins.
-// (The read-only pass over X differs by 1 % between the two; it keeps rotation 0.)
+// (The read-only pass over X differs by ~1 % between the two: calibrated the same way, on X, for handles of the Gram form.)
 hipError_t big_malloc(void** p, size_t bytes);
 void calibrate_rot(rri_ctx* c) {
     if (c->rot_done) return;
     c->rot_done = true;
     if (g_pass_rot >= 0 || !g_rot_cal) return;
-    const bool resid = c->explicit_resid && !c->weighted;
+    const bool resid = resid_sched(c);
     const bool wdense = c->weighted && !c->sparse;
-    if (!(resid || wdense) || (double)c->n * (double)c->d < 1.0e8 || c->npanels * c->nrb < 64) return;
+    const bool plain = !c->weighted && !resid && !c->sparse && !c->prm.fix_T;      // the Gram form: the read-only pass over X
+    if (!(resid || wdense || plain) || (double)c->n * (double)c->d < 1.0e8 || c->npanels * c->nrb < 64) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return; }
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return; }
+    if (plain) {
+        // the read-only pass moves by ~1 % with the rotation (0.643 against 0.650 ms at BASELINE config 3, the same way in every
+        // round of three processes): the same calibration on X, 8 passes once per handle
+        float best = -1.0f;
+        int best_rot = 0;
+        for (int rot = -1; rot < 2; ++rot) {                 // -1: two warm passes
+            c->rot_x = std::max(rot, 0);
+            for (int rep = 0; rep < (rot < 0 ? 2 : 3); ++rep) {
+                if (rot >= 0 && rep == 1) (void)hipEventRecord(e0, c->stream);
+                DISPATCH(c, (L::template pass<true, true>(c, 0, 0)));
+            }
+            if (rot < 0) continue;
+            (void)hipEventRecord(e1, c->stream);
+            float ms = 0.0f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = -1.0f; break; }
+            if (getenv("RRI_ROT_DEBUG")) fprintf(stderr, "rri: tile rotation %d: %.4f ms per read-only pass\n", rot, ms / 2.0f);
+            if (best < 0.0f || ms < best) { best = ms; best_rot = rot; }
+        }
+        c->rot_x = best > 0.0f ? best_rot : 0;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        c->carry_valid = false;
+        c->carry_topic = -1;
+        return;
+    }
     auto refresh = [&]() {
         if (resid) r_refresh(c);
         else w_refresh(c);
@@ -1685,7 +1711,7 @@ bool enqueue_wsweep(rri_ctx* c, int sweep, int t0) {
 // sweeps [cur .. s_end) of the current call
 void enqueue_range(rri_ctx* c, Cursor cur, int s_end) {
     const int k = c->k;
-    if (cur.sweep < s_end && (c->weighted || resid_sched(c))) calibrate_rot(c);
+    if (cur.sweep < s_end) calibrate_rot(c);
     if (c->weighted) {
         for (int s = cur.sweep; s < s_end; ++s) {
             const int t0 = (s == cur.sweep) ? cur.topic : 0;

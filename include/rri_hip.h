@@ -146,9 +146,9 @@ rri_status rri_set_params(rri_ctx* ctx, const rri_params* p);
  * a sweep as ONE launch over the rows of W, the column checks of nmf.py:471-476 in topic order after it (k n + k^2 doubles
  * of device memory more, allocated at the first such sweep; RRI_WSWEEP=0 in the environment of rri_create: topic by topic);
  * dense weighted handles whose W_mat is 0 / 1 and below 12 % set keep a second bit-packed copy of it (n d / 8 bytes);
- * handles that keep a residual (RRI_UNWEIGHTED_RESIDUAL, dense weighted) of 10^8 elements or more time their read-modify-write
- * pass once, before the first sweep, under the two ways of dealing its tiles to the XCDs and keep the faster (~12 ms; the
- * residual is rewritten with its own values meanwhile; RRI_ROT_CAL=0: not). */
+ * handles of 10^8 elements or more time their pass once, before the first sweep, under the two ways of dealing its tiles to
+ * the XCDs and keep the faster (the read-only pass over X: ~5 ms; the read-modify-write pass over a stored residual --
+ * RRI_UNWEIGHTED_RESIDUAL, dense weighted --: ~12 ms, the residual rewritten with its own values meanwhile; RRI_ROT_CAL=0: not). */
 rri_status rri_sweep(rri_ctx* ctx, int32_t n_sweeps, int32_t* sweeps_done);
 rri_status rri_resume(rri_ctx* ctx, int32_t* sweeps_done);
 rri_status rri_pending_event(rri_ctx* ctx, rri_event* ev);
